@@ -1,0 +1,174 @@
+"""bench.py -- env-steps/sec of the PPO rollout + GAE hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: a T=128-step rollout of the env batch
+(policy forward + action sampling + fused env step/reset kernel per time step), the
+bootstrap-value forward over the terminal observations, and the GAE kernel -- the bracket the
+reference times as `env_steps_per_sec` (reference src/ppo.py:544-560).  Workload = BASELINE.json
+configs[1]: CartPole, N = 65536 envs x T = 128 per GPU.  With --gpus N every rank runs that
+workload on its own envs (weak scaling; the path has no data-path collective -- envs shard by
+batch, and the gradient all-reduce belongs to the update, outside this bracket).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the GAE kernel (the HBM-bound kernel the north
+star sets a target for), timed with HIP events on the launch stream inside the timed region.
+`cpu_baseline` is the oracle's serial per-env Python restatement of the reference's CPU path
+(oracle/pyref.py, kind "port"), timed on rank 0 at N=1 on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+GAE_BYTES_PER_ELEM = 24        # r, v, done, trunc, end_value read + adv written
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--env", default="cartpole", choices=["cartpole", "acrobot"])
+    p.add_argument("--num-envs", type=int, default=65536, help="envs PER GPU")
+    p.add_argument("--rollout-len", type=int, default=128)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-envs", type=int, default=1024)
+    p.add_argument("--seed", type=int, default=0)
+    return p.parse_args()
+
+
+def cpu_baseline(kind, n_envs, T, seed):
+    """The reference's CPU path shape, restated (oracle/pyref.py): one Python env object per env,
+    serial stepping, per-element tensor writes, T-iteration torch-CPU GAE; one core."""
+    from oracle import pyref
+    from ppo_amd import Agent
+    from ppo_amd.envs import make_spaces, KINDS
+    torch.manual_seed(seed)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        obs_space, act_space = make_spaces(KINDS[kind])
+        agent = Agent(obs_space, act_space, conv_net=0, joint_net=1, device="cpu")
+        rng = np.random.default_rng(seed)
+        envs = [pyref.make_env(kind, np.random.default_rng(rng.integers(1 << 62))) for _ in range(n_envs)]
+        t_states = torch.stack([torch.tensor(e.reset()[0]) for e in envs])
+
+        def policy(s):
+            a, lp, v, _ = agent.get_actions_and_values(s, None)
+            return a, lp, v
+
+        t0 = time.perf_counter()
+        out = pyref.serial_rollout(envs, t_states, policy, T)
+        with torch.no_grad():
+            ev = agent.get_values(out["end_states"])
+            pyref.gae_torch(out["rewards"], out["values"], ev, out["done"], out["trunc"], 0.99, 0.95)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthreads)
+    return {"value": n_envs * T / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{kind} N={n_envs} envs x T={T} (one rollout + bootstrap forward + torch-CPU GAE), "
+                      f"{dt:.1f} s on 1 core; per-env cost is constant, so N=65536 extrapolates linearly"}
+
+
+def main():
+    args = parse()
+    from ppo_amd import PPO, Agent, SyncVecEnv, ops
+    from ppo_amd import dist as D
+    from ppo_amd.envs import DeviceEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: ppo_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if world > 1:
+        D.init_from_env("nccl")
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    N, T, kind = args.num_envs, args.rollout_len, args.env
+    torch.manual_seed(args.seed + rank)
+    ppo = PPO(0.99, 0.95, 1, 1, 0, 1, True, seed=args.seed)
+    probe = DeviceEnv(kind)
+    ppo.agent = agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
+    D.broadcast_params(agent)
+    ppo.vec_env = ve = SyncVecEnv(lambda: DeviceEnv(kind), N, T, 0, 0.0, agent, seed=args.seed, env_base=rank * N)
+
+    gae_events = []
+
+    def hot_path_step(record):
+        ve.rollout()
+        with torch.no_grad():
+            end_values = agent.get_values(ve.end_states)
+            ev_dense = ppo._scatter_end_values(ve, end_values)
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95)
+            if record:
+                e1.record()
+                gae_events.append((e0, e1))
+        return adv
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hot_path_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hot_path_step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    gae_ms = float(np.mean([a.elapsed_time(b) for a, b in gae_events]))
+    gae_bytes = GAE_BYTES_PER_ELEM * T * N
+    achieved = gae_bytes / (gae_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "gae_pmc_traffic.json")
+    if os.path.exists(pmc):  # per-launch HBM bytes from rocprofv3 --pmc passes at this shape
+        rec = json.load(open(pmc))
+        if rec.get("T") == T and rec.get("N") == N:
+            traffic = rec.get("hbm_bytes_per_launch")
+
+    if rank == 0:
+        total_steps = args.steps * T * N * world
+        line = {
+            "metric": "env-steps/sec (rollout+GAE)", "value": total_steps / elapsed, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 env state / f32 buffers", "data": "synthetic",
+            "config": {"workload": f"{kind} batched stepping + GAE, N={N} envs/GPU x T={T}, dense 64-64 tanh policy "
+                                   f"(joint net) on PyTorch-ROCm, BASELINE configs[1]",
+                       "num_envs_per_gpu": N, "rollout_len": T, "parallelism": f"env-sharded x{world}, no data-path collective"},
+            "roofline": {"kernel": "k_gae (ppo_gae_dense)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(kind, args.cpu_sample_envs, T, args.seed)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+/*
+ * ppo_amd.h -- C ABI of libppo_amd.so: the MI355X (gfx950) kernels for the PPO
+ * rollout-and-advantage hot path of BradleyGS1/PPO.
+ *
+ * The reference is pure Python and has no FFI of its own; every entry
+ * point below cites the reference code (file:line under /root/reference) whose work it
+ * takes over.  The Python surface in ppo_amd/ppo.py (same class/method names as
+ * src/ppo.py) binds these with ctypes (ppo_amd/_lib.py); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer (hipMalloc / torch tensor.data_ptr()) unless
+ *     marked "host".  The library never allocates, frees or retains caller memory and
+ *     never synchronises: every call enqueues kernels on `stream` and returns.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Return value: 0 = hipSuccess, otherwise a hipError_t (hipErrorInvalidValue = 1
+ *     for rejected arguments; nothing has been launched in that case).
+ *   - Matrices are row-major [T, N]: element (t, n) at t*N + n  (the layout of the
+ *     reference's rollout buffers, src/ppo.py:309-315).
+ *   - Re-entrant; no global state.  One host thread per device (the reference is
+ *     single-threaded, so no concurrency contract is inherited).
+ */
+#ifndef PPO_AMD_H
+#define PPO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPO_AMD_ABI_VERSION 1
+
+#define PPO_ENV_CARTPOLE 0 /* CartPole-v1: obs_dim 4, actions {0,1}   */
+#define PPO_ENV_ACROBOT 1  /* Acrobot-v1:  obs_dim 6, actions {0,1,2} */
+
+int ppo_abi_version(void);
+
+/* Observation width of an env kind (4 / 6), or -1. */
+int ppo_env_obs_dim(int kind);
+
+/*
+ * Reset N envs and write their first observations.
+ * Replaces SyncVecEnv.vec_reset (src/ppo.py:269-275): N x env.reset() + packing into
+ * states[N, obs_dim] f32.
+ *   state      [N,4] f64  physics state (fp64 like gymnasium's), overwritten
+ *   elapsed    [N]   i32  TimeLimit step counter, zeroed
+ *   ep_ret     [N]   f32, ep_len [N] i32: RecordEpisodeStatistics accumulators, zeroed
+ *   episode    [N]   u32  reset counter: read as the Philox stream position, then +1
+ *   reset_draw [N,4] f64  uniforms in [0,1) to build the initial state from, or NULL to
+ *                         draw them from Philox4x32-10 keyed (seed; env_base+n, episode)
+ *   obs_out    [N,obs_dim] f32
+ */
+int ppo_env_reset(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len,
+                  uint32_t *episode, const double *reset_draw, uint64_t seed,
+                  uint64_t env_base, float *obs_out, int N, void *stream);
+
+/*
+ * One transition of N envs, fused with the per-actor bookkeeping of one iteration of
+ * the rollout loop.  Replaces SyncVecEnv.vec_step (src/ppo.py:283-302), the env physics
+ * behind env.step (gymnasium CartPoleEnv/AcrobotEnv + TimeLimit(500) +
+ * RecordEpisodeStatistics; call sites src/env_cartpole.py:7-8, src/env_acrobot.py:7-8),
+ * SyncVecEnv.env_reset (src/ppo.py:277-281) and the actor loop src/ppo.py:342-388:
+ *   - done[n]  = terminated, trunc[n] = TimeLimit truncation (both may be 1)
+ *   - if neither is set and is_last != 0: trunc[n] += 1 and the env is NOT reset
+ *     (forced truncation at the last rollout step, src/ppo.py:352-356)
+ *   - if done+trunc > 0: the terminal observation goes to term_obs[n,:] (:377-379) and,
+ *     unless the truncation was forced, the env is reset and obs_out[n,:] holds the
+ *     reset observation (:381-382)
+ *   - otherwise term_obs[n,:] is left untouched
+ *   action     [N] i32
+ *   reward     [N] f32, done [N] i32, trunc [N] i32, obs_out [N,obs_dim] f32
+ *   term_obs   [N,obs_dim] f32 or NULL
+ *   ret_ring / len_ring [N,ring] f32/i32 + ring_cnt [N] i32: last-`ring` finished
+ *              episode returns / lengths per env (RecordEpisodeStatistics deques read at
+ *              src/ppo.py:404-417), or all NULL
+ * Other arguments as in ppo_env_reset.
+ */
+int ppo_env_step(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len,
+                 uint32_t *episode, const int *action, const double *reset_draw,
+                 uint64_t seed, uint64_t env_base, float *obs_out, float *term_obs,
+                 float *reward, int *done, int *trunc, float *ret_ring, int *len_ring,
+                 int *ring_cnt, int ring, int N, int is_last, void *stream);
+
+/*
+ * GAE(lambda) reverse-time scan, dense bootstrap values.
+ * Replaces PPO.compute_advantages (src/ppo.py:452-488) when the bootstrap value of the
+ * terminal observation is stored at the (t, n) where the flag was raised:
+ *   end_value_dense [T,N] f32 (read only where trunc != 0)
+ *   adv [T,N] f32 out;  ret [T,N] f32 out or NULL (adv + values, src/ppo.py:498)
+ * Arithmetic per element is the reference's, one rounding per operation, so the result
+ * is bit-identical to the reference for flags in {0,1}.
+ */
+int ppo_gae_dense(const float *rewards, const float *values, const float *end_value_dense,
+                  const int *done, const int *trunc, double gamma, double lam, float *adv,
+                  float *ret, int T, int N, void *stream);
+
+/* Bytes of device workspace ppo_gae_ragged needs for N columns. */
+size_t ppo_gae_ragged_workspace_bytes(int N);
+
+/*
+ * GAE(lambda) with the reference's ragged, actor-major end_values[E] list: the exact
+ * drop-in for PPO.compute_advantages(rewards, values, end_values, done_flags,
+ * trunc_flags) (src/ppo.py:452-488), including ep_counts/cumsum indexing (:468-469), the
+ * per-step index decrement by done+trunc (:480), negative-index wrap-around, and the
+ * (1 - terminations) arithmetic when both flags are set (:476-479).
+ * Where torch would raise IndexError (index outside [-E, E)) the kernel uses 0.0 and
+ * sets *err_flag (i32, may be NULL) to 1 instead of faulting.
+ */
+int ppo_gae_ragged(const float *rewards, const float *values, const float *end_values,
+                   long E, const int *done, const int *trunc, double gamma, double lam,
+                   float *adv, int T, int N, void *workspace, size_t workspace_bytes,
+                   int *err_flag, void *stream);
+
+/* Bytes of device workspace ppo_adv_stats / ppo_loss_fwd_bwd need for B samples. */
+size_t ppo_loss_workspace_bytes(long B);
+
+/*
+ * {count, mean, M2 = sum (a - mean)^2} of adv[0..B) in fp64 -> stats3 (device, 3 f64).
+ * Feeds the minibatch advantage normalisation of src/ppo.py:500-501
+ * (mean, unbiased std).  Separate from the loss so that data-parallel ranks can merge
+ * their triples before normalising.
+ */
+int ppo_adv_stats(const float *adv, long B, double *stats3, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
+/*
+ * Fused PPO minibatch loss, forward and backward.  Replaces the ratio at
+ * src/ppo.py:595 and PPO.compute_losses (src/ppo.py:490-527) plus the autograd backward
+ * of both losses.
+ *   x       [B] f32  new log-probs (ratio_input = 0) or probability ratios (= 1, the
+ *                    signature compute_losses itself has)
+ *   old_lp  [B] f32  old log-probs (ignored / may be NULL when ratio_input = 1)
+ *   new_v, old_v, adv [B] f32
+ *   stats3  device {count, mean, M2} used when norm_adv != 0 (may be NULL otherwise)
+ *   out4    device f32[4] = policy_loss, value_loss, clip_frac, kl_div
+ *   g_x     [B] f32  d policy_loss / d x  (NULL to skip);  g_v [B] f32 d value_loss / d new_v
+ * Gradient tie rules are torch autograd's (minimum/maximum split 1/2-1/2, clamp passes
+ * gradient on the closed interval).
+ */
+int ppo_loss_fwd_bwd(const float *x, const float *old_lp, const float *new_v,
+                     const float *old_v, const float *adv, const double *stats3,
+                     double clip, int norm_adv, int clip_va, int ratio_input, long B,
+                     float *out4, float *g_x, float *g_v, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
+/*
+ * Categorical sampling for the rollout's policy step: for each row of logits[N,A]
+ * draw an action with Philox4x32-10 keyed (seed; env_base+n, step) and return its
+ * log-probability.  Replaces torch.distributions.Categorical(logits).sample() and
+ * .log_prob() at src/ppo.py:186-189,212 inside SyncVecEnv.rollout (:337).
+ *   action [N] i32, logp [N] f32.  A <= 32.
+ */
+int ppo_categorical_sample(const float *logits, int A, uint64_t seed, uint64_t env_base,
+                           uint64_t step, int *action, float *logp, int N, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPO_AMD_H */

@@ -1,0 +1,297 @@
+// GAE(lambda) reverse-time scan over the [T, N] rollout buffer -- gfx950.
+//
+// Replaces PPO.compute_advantages (reference src/ppo.py:452-488).  HBM-bound: 24 B per
+// (t, n) element (r, v, done, trunc, end_value read; adv written), ~6 flops.  No MFMA.
+//
+// Mapping: one lane owns VEC adjacent env columns and walks time backwards; consecutive
+// lanes own consecutive columns, so every wave-level load/store is one contiguous
+// 64*4*VEC-byte row segment (fully coalesced).  The recurrence itself is two dependent
+// f32 ops per step; what has to be engineered is memory-level parallelism, because a
+// [128, 65536] buffer is only 1024 waves wide (4 per CU).  Each lane therefore keeps TWO
+// blocks of U rows x 5 arrays in flight in registers (software double buffering): the
+// loads of block k+1 are issued before block k is consumed.
+//
+// Arithmetic: exactly the reference's sequence of f32 operations, one rounding each
+// (the library is built with -ffp-contract=off), so results are bit-identical to
+// torch-CPU for flags in {0,1} and reproduce its (1 - terminations) arithmetic otherwise.
+#include "common.h"
+
+namespace {
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using F = float; using I = int; };
+template <> struct VecT<2> { using F = float2; using I = int2; };
+template <> struct VecT<4> { using F = float4; using I = int4; };
+
+template <int VEC> __device__ __forceinline__ float fget(const typename VecT<VEC>::F &v, int k);
+template <> __device__ __forceinline__ float fget<1>(const float &v, int) { return v; }
+template <> __device__ __forceinline__ float fget<2>(const float2 &v, int k) { return k == 0 ? v.x : v.y; }
+template <> __device__ __forceinline__ float fget<4>(const float4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+template <int VEC> __device__ __forceinline__ int iget(const typename VecT<VEC>::I &v, int k);
+template <> __device__ __forceinline__ int iget<1>(const int &v, int) { return v; }
+template <> __device__ __forceinline__ int iget<2>(const int2 &v, int k) { return k == 0 ? v.x : v.y; }
+template <> __device__ __forceinline__ int iget<4>(const int4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+template <int VEC> __device__ __forceinline__ void fset(typename VecT<VEC>::F &v, int k, float x);
+template <> __device__ __forceinline__ void fset<1>(float &v, int, float x) { v = x; }
+template <> __device__ __forceinline__ void fset<2>(float2 &v, int k, float x) { if (k == 0) v.x = x; else v.y = x; }
+template <> __device__ __forceinline__ void fset<4>(float4 &v, int k, float x) { if (k == 0) v.x = x; else if (k == 1) v.y = x; else if (k == 2) v.z = x; else v.w = x; }
+
+template <int VEC, int U, bool DENSE_EV> struct RowBlock {
+    typename VecT<VEC>::F r[U], v[U], ev[DENSE_EV ? U : 1];
+    typename VecT<VEC>::I d[U], tr[U];
+};
+
+struct GaeArgs {
+    const float *r, *v, *ev;   // ev: dense [T,N] or ragged [E]
+    const int *done, *trunc;
+    float *adv, *ret;
+    const long *idx0;          // ragged only: start index per column (cumsum - 1)
+    long E;
+    int *err;
+    float g, gl;
+    int T, N;
+};
+
+template <int VEC, int U, bool DENSE_EV>
+__device__ __forceinline__ void load_block(RowBlock<VEC, U, DENSE_EV> &b, const GaeArgs &a, size_t col, int t_top)
+{
+    using F = typename VecT<VEC>::F;
+    using I = typename VecT<VEC>::I;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t o = (size_t)(t_top - u) * (size_t)a.N + col;
+        b.r[u] = *reinterpret_cast<const F *>(a.r + o);
+        b.v[u] = *reinterpret_cast<const F *>(a.v + o);
+        b.d[u] = *reinterpret_cast<const I *>(a.done + o);
+        b.tr[u] = *reinterpret_cast<const I *>(a.trunc + o);
+        if (DENSE_EV) b.ev[u] = *reinterpret_cast<const F *>(a.ev + o);
+    }
+}
+
+// One reverse step of one column: reference src/ppo.py:476-486.
+__device__ __forceinline__ float gae_step(float r, float v, int d, int tr, float ev, float g, float gl,
+                                          float &nv, float &na)
+{
+    const int term = d + tr;                 // :476
+    const float keep = (float)(1 - term);
+    nv = keep * nv + (float)tr * ev;         // :478
+    na = keep * na;                          // :479
+    const float delta = r + g * nv - v;      // :482
+    const float adv = delta + gl * na;       // :483
+    nv = v;                                  // :485
+    na = adv;                                // :486
+    return adv;
+}
+
+template <int VEC, int U, bool DENSE_EV>
+__device__ __forceinline__ void consume_block(const RowBlock<VEC, U, DENSE_EV> &b, const GaeArgs &a, size_t col,
+                                              int t_top, float (&nv)[VEC], float (&na)[VEC], long (&idx)[VEC])
+{
+    using F = typename VecT<VEC>::F;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        F out, rout;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int d = iget<VEC>(b.d[u], k), tr = iget<VEC>(b.tr[u], k);
+            float ev = 0.0f;
+            if (DENSE_EV) {
+                ev = tr ? fget<VEC>(b.ev[u], k) : 0.0f;  // buffer is only defined where flagged
+            } else {
+                if (tr) {                                 // rare, data-dependent gather (:478)
+                    long j = idx[k] < 0 ? idx[k] + a.E : idx[k];
+                    if (j >= 0 && j < a.E) ev = a.ev[j];
+                    else if (a.err) *a.err = 1;           // torch would raise IndexError
+                }
+                idx[k] -= (long)(d + tr);                 // :480
+            }
+            const float v = fget<VEC>(b.v[u], k);
+            const float adv = gae_step(fget<VEC>(b.r[u], k), v, d, tr, ev, a.g, a.gl, nv[k], na[k]);
+            fset<VEC>(out, k, adv);
+            fset<VEC>(rout, k, adv + v);                  // returns, src/ppo.py:498
+        }
+        const size_t o = (size_t)(t_top - u) * (size_t)a.N + col;
+        *reinterpret_cast<F *>(a.adv + o) = out;
+        if (a.ret) *reinterpret_cast<F *>(a.ret + o) = rout;
+    }
+}
+
+template <int VEC, int U, bool DENSE_EV>
+__global__ void __launch_bounds__(256) k_gae(GaeArgs a)
+{
+    const size_t col = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (col >= (size_t)a.N) return;
+
+    float nv[VEC], na[VEC];
+    long idx[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        nv[k] = 0.0f; na[k] = 0.0f;                       // :470-471
+        idx[k] = DENSE_EV ? 0 : a.idx0[col + k];          // :469
+    }
+
+    const int nblk = a.T / U;
+    int t = a.T - 1;
+    RowBlock<VEC, U, DENSE_EV> cur, nxt;
+    if (nblk > 0) load_block<VEC, U, DENSE_EV>(cur, a, col, t);
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 1 < nblk) load_block<VEC, U, DENSE_EV>(nxt, a, col, t - U);  // prefetch next block
+        consume_block<VEC, U, DENSE_EV>(cur, a, col, t, nv, na, idx);
+        cur = nxt;
+        t -= U;
+    }
+    for (; t >= 0; --t) {                                 // T % U leftover rows
+        RowBlock<VEC, 1, DENSE_EV> one;
+        load_block<VEC, 1, DENSE_EV>(one, a, col, t);
+        consume_block<VEC, 1, DENSE_EV>(one, a, col, t, nv, na, idx);
+    }
+}
+
+// --- ragged pre-pass: ep_counts (src/ppo.py:468) and cumsum - 1 (:469) ------------
+__global__ void __launch_bounds__(256) k_ep_counts(const int *done, const int *trunc, long *counts, int T, int N)
+{
+    const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (size_t)N) return;
+    long c = 0;
+    for (int t = 0; t < T; ++t) {
+        const size_t o = (size_t)t * N + n;
+        const int d = done[o], tr = trunc[o];
+        c += d + tr - d * tr;
+    }
+    counts[n] = c;
+}
+
+// Single-workgroup inclusive scan (N is at most a few 100k columns; the ragged form is
+// the compatibility path).  In place: counts[n] <- cumsum(counts)[n] - 1.
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_PER_THREAD = 16;
+__global__ void __launch_bounds__(SCAN_THREADS) k_cumsum_minus1(long *counts, int N)
+{
+    __shared__ long wave_tot[SCAN_THREADS / PPO_WAVE];
+    __shared__ long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (long base = 0; base < N; base += (long)SCAN_THREADS * SCAN_PER_THREAD) {
+        const long first = base + (long)tid * SCAN_PER_THREAD;
+        long loc[SCAN_PER_THREAD];
+        long sum = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_PER_THREAD; ++i) {
+            const long n = first + i;
+            sum += (n < N) ? counts[n] : 0;
+            loc[i] = sum;
+        }
+        long incl = sum;  // inclusive scan of per-thread sums across the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long y = __shfl_up(incl, off, PPO_WAVE);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        long wave_off = 0, total = 0;
+        for (int w = 0; w < SCAN_THREADS / PPO_WAVE; ++w) {
+            const long wt = wave_tot[w];
+            if (w < wid) wave_off += wt;
+            total += wt;
+        }
+        const long excl = carry_s + wave_off + (incl - sum);
+#pragma unroll
+        for (int i = 0; i < SCAN_PER_THREAD; ++i) {
+            const long n = first + i;
+            if (n < N) counts[n] = excl + loc[i] - 1;
+        }
+        __syncthreads();
+        if (tid == 0) carry_s += total;
+        __syncthreads();
+    }
+}
+
+template <int VEC, int U, bool DENSE_EV> int launch_gae(const GaeArgs &a, hipStream_t s)
+{
+    const long threads = a.N / VEC;
+    const long waves = (threads + 63) / 64;
+    const int block = waves <= 2048 ? 64 : 256;  // few columns: spread the waves over all CUs
+    const long grid = (threads + block - 1) / block;
+    hipLaunchKernelGGL((k_gae<VEC, U, DENSE_EV>), dim3((unsigned)grid), dim3(block), 0, s, a);
+    return ppo_launch_status();
+}
+
+int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s)
+{
+    switch (variant) {
+    case 0: return launch_gae<1, 8, true>(a, s);
+    case 1: return launch_gae<1, 4, true>(a, s);
+    case 2: return launch_gae<1, 16, true>(a, s);
+    case 3: return launch_gae<2, 4, true>(a, s);
+    case 4: return launch_gae<2, 8, true>(a, s);
+    case 5: return launch_gae<4, 2, true>(a, s);
+    case 6: return launch_gae<4, 4, true>(a, s);
+    case 7: return launch_gae<1, 2, true>(a, s);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+int variant_vec(int variant) { return variant == 3 || variant == 4 ? 2 : (variant == 5 || variant == 6 ? 4 : 1); }
+
+}  // namespace
+
+extern "C" {
+
+// Tuning hook (not part of the public header): pick a (VEC, U) instantiation explicitly.
+int ppo_gae_dense_variant(const float *rewards, const float *values, const float *end_value_dense,
+                          const int *done, const int *trunc, double gamma, double lam, float *adv,
+                          float *ret, int T, int N, int variant, void *stream)
+{
+    PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
+    PPO_REQUIRE(T >= 0 && N >= 0);
+    if (T == 0 || N == 0) return 0;
+    const int vec = variant_vec(variant);
+    const size_t al = 4 * (size_t)vec;
+    PPO_REQUIRE(N % vec == 0);
+    PPO_REQUIRE(ppo_aligned(rewards, al) && ppo_aligned(values, al) && ppo_aligned(end_value_dense, al) &&
+                ppo_aligned(done, al) && ppo_aligned(trunc, al) && ppo_aligned(adv, al) &&
+                (!ret || ppo_aligned(ret, al)));
+    GaeArgs a{rewards, values, end_value_dense, done, trunc, adv, ret, nullptr, 0, nullptr,
+              (float)gamma, (float)(gamma * lam), T, N};
+    return launch_gae_dense_variant(a, variant, (hipStream_t)stream);
+}
+
+int ppo_gae_dense(const float *rewards, const float *values, const float *end_value_dense,
+                  const int *done, const int *trunc, double gamma, double lam, float *adv,
+                  float *ret, int T, int N, void *stream)
+{
+    PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
+    // Variant choice (measured on MI355X): VEC=1/U=8 unless the caller's
+    // shape allows nothing else; wider VEC needs N % VEC == 0 and aligned bases.
+    return ppo_gae_dense_variant(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
+                                 0, stream);
+}
+
+size_t ppo_gae_ragged_workspace_bytes(int N) { return N > 0 ? (size_t)N * sizeof(long) : 0; }
+
+int ppo_gae_ragged(const float *rewards, const float *values, const float *end_values, long E,
+                   const int *done, const int *trunc, double gamma, double lam, float *adv, int T,
+                   int N, void *workspace, size_t workspace_bytes, int *err_flag, void *stream)
+{
+    PPO_REQUIRE(rewards && values && done && trunc && adv);
+    PPO_REQUIRE(T >= 0 && N >= 0 && E >= 0);
+    PPO_REQUIRE(E == 0 || end_values);
+    if (T == 0 || N == 0) return 0;
+    PPO_REQUIRE(workspace && workspace_bytes >= ppo_gae_ragged_workspace_bytes(N));
+    PPO_REQUIRE(ppo_aligned(workspace, 8));
+    hipStream_t s = (hipStream_t)stream;
+    long *idx0 = reinterpret_cast<long *>(workspace);
+    hipLaunchKernelGGL(k_ep_counts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, done, trunc, idx0, T, N);
+    int rc = ppo_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cumsum_minus1, dim3(1), dim3(SCAN_THREADS), 0, s, idx0, N);
+    rc = ppo_launch_status();
+    if (rc) return rc;
+    GaeArgs a{rewards, values, end_values, done, trunc, adv, nullptr, idx0, E, err_flag,
+              (float)gamma, (float)(gamma * lam), T, N};
+    return launch_gae<1, 8, false>(a, s);
+}
+
+}  // extern "C"

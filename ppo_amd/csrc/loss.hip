@@ -1,0 +1,276 @@
+// Fused PPO minibatch loss (forward + backward) and advantage statistics -- gfx950.
+//
+// Replaces the ratio at reference src/ppo.py:595 and PPO.compute_losses (:490-527) plus
+// the autograd backward of policy_loss and value_loss.  HBM-bound: 20 B/sample read
+// (+4 for the statistics pre-pass), 8 B/sample of gradients written.  No MFMA.
+//
+// Structure: grid-stride over float4 groups (16 B per lane per array, the coalescing
+// sweet spot), per-lane fp64 partial sums, wave64 butterfly (DPP) reduction, one LDS
+// stage across the block's waves, one fp64 partial row per block in the caller's
+// workspace, then a one-block finalize kernel that adds the rows in index order.  The
+// grid depends only on B, so results are run-to-run deterministic.
+//
+// Elementwise arithmetic is the reference's f32 sequence, one rounding per operation
+// (-ffp-contract=off); only the reductions differ (fp64 here, f32 tree in torch).
+#include "common.h"
+
+namespace {
+
+constexpr int LOSS_BLOCK = 256;
+constexpr int LOSS_MAX_BLOCKS = 2048;  // 256 CUs x 8 blocks (guide: Guideline 11)
+
+__host__ __device__ inline long loss_groups(long B) { return (B + 3) / 4; }
+
+inline int loss_grid(long B)
+{
+    long blocks = (loss_groups(B) + LOSS_BLOCK - 1) / LOSS_BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > LOSS_MAX_BLOCKS) blocks = LOSS_MAX_BLOCKS;
+    return (int)blocks;
+}
+
+// Sum NV doubles per lane over the block; lane 0 of wave 0 writes them to dst[0..NV).
+template <int NV> __device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double *dst)
+{
+    __shared__ double part[LOSS_BLOCK / PPO_WAVE][NV];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) part[wid][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double s = 0.0;
+            for (int w = 0; w < LOSS_BLOCK / PPO_WAVE; ++w) s += part[w][k];
+            dst[k] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const float *p, long i, long B, bool vec)
+{
+    if (vec && i + 3 < B) return *reinterpret_cast<const float4 *>(p + i);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i + 0 < B) v.x = p[i + 0];
+    if (i + 1 < B) v.y = p[i + 1];
+    if (i + 2 < B) v.z = p[i + 2];
+    if (i + 3 < B) v.w = p[i + 3];
+    return v;
+}
+
+__device__ __forceinline__ void st4(float *p, long i, long B, bool vec, const float4 &v)
+{
+    if (vec && i + 3 < B) { *reinterpret_cast<float4 *>(p + i) = v; return; }
+    if (i + 0 < B) p[i + 0] = v.x;
+    if (i + 1 < B) p[i + 1] = v.y;
+    if (i + 2 < B) p[i + 2] = v.z;
+    if (i + 3 < B) p[i + 3] = v.w;
+}
+
+// ---- advantage statistics: shifted sums, K = adv[0] -------------------------------
+__global__ void __launch_bounds__(LOSS_BLOCK) k_adv_stats_partial(const float *adv, long B, double *partials, bool vec)
+{
+    const float K = adv[0];
+    double acc[2] = {0.0, 0.0};
+    const long G = loss_groups(B);
+    for (long g = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x; g < G; g += (long)gridDim.x * LOSS_BLOCK) {
+        const long i = g * 4;
+        const float4 a = ld4(adv, i, B, vec);
+        const float e[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < B) {
+                const double d = (double)e[k] - (double)K;
+                acc[0] += d;
+                acc[1] += d * d;
+            }
+        }
+    }
+    block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * 2);
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_adv_stats_final(const float *adv, long B, const double *partials,
+                                                              int nblocks, double *stats3)
+{
+    double acc[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += LOSS_BLOCK) {
+        acc[0] += partials[(size_t)b * 2 + 0];
+        acc[1] += partials[(size_t)b * 2 + 1];
+    }
+    __shared__ double tot[2];
+    block_reduce_store<2>(acc, tot);
+    if (threadIdx.x == 0) {
+        const double n = (double)B, K = (double)adv[0];
+        const double S = tot[0], Q = tot[1];
+        stats3[0] = n;
+        stats3[1] = K + S / n;
+        double m2 = Q - S * S / n;
+        stats3[2] = m2 > 0.0 ? m2 : 0.0;
+    }
+}
+
+// ---- loss forward + backward ---------------------------------------------------------
+struct LossArgs {
+    const float *x, *old_lp, *new_v, *old_v, *adv;
+    const double *stats3;
+    float *g_x, *g_v;
+    double *partials;
+    float lo, hi, epsf;
+    long B;
+    int norm_adv, clip_va, ratio_input;
+    bool vec;
+};
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_loss_partial(LossArgs a)
+{
+    float mean_f = 0.0f, denom_f = 1.0f;
+    if (a.norm_adv) {
+        const double n = a.stats3[0];
+        mean_f = (float)a.stats3[1];
+        const float std_f = (float)sqrt(a.stats3[2] / (n - 1.0));  // unbiased (torch.std), NaN at B=1
+        denom_f = std_f + 1e-8f;                                   // src/ppo.py:501
+    }
+    const float invB = 1.0f / (float)a.B;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const long G = loss_groups(a.B);
+    for (long g = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x; g < G; g += (long)gridDim.x * LOSS_BLOCK) {
+        const long i = g * 4;
+        const float4 x4 = ld4(a.x, i, a.B, a.vec);
+        const float4 nv4 = ld4(a.new_v, i, a.B, a.vec);
+        const float4 ov4 = ld4(a.old_v, i, a.B, a.vec);
+        const float4 ad4 = ld4(a.adv, i, a.B, a.vec);
+        float4 ol4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!a.ratio_input) ol4 = ld4(a.old_lp, i, a.B, a.vec);
+        const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, nvs[4] = {nv4.x, nv4.y, nv4.z, nv4.w};
+        const float ovs[4] = {ov4.x, ov4.y, ov4.z, ov4.w}, ads[4] = {ad4.x, ad4.y, ad4.z, ad4.w};
+        const float ols[4] = {ol4.x, ol4.y, ol4.z, ol4.w};
+        float gx[4], gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool live = i + k < a.B;
+            const float rho = a.ratio_input ? xs[k] : expf(xs[k] - ols[k]);  // :595
+            float adv = ads[k];
+            const float ret = adv + ovs[k];                                   // :498
+            if (a.norm_adv) adv = (adv - mean_f) / denom_f;                   // :501
+            const float rc = rho < a.lo ? a.lo : (rho > a.hi ? a.hi : rho);   // :503
+            const float w = rho * adv, c = rc * adv;                          // :504-505
+            const float m = w < c ? w : c;                                    // :508
+            const bool inside = (rho >= a.lo) && (rho <= a.hi);
+            float gr;
+            if (w < c) gr = adv;
+            else if (w > c) gr = inside ? adv : 0.0f;
+            else gr = 0.5f * adv + (inside ? 0.5f * adv : 0.0f);              // torch.minimum tie
+            gr = -gr * invB;
+            gx[k] = a.ratio_input ? gr : gr * rho;
+
+            const float v = nvs[k];
+            const float e = ret - v;
+            const float se = e * e;                                           // :513 / :518
+            float vterm, gvk;
+            if (a.clip_va) {
+                const float vlo = ovs[k] - a.epsf, vhi = ovs[k] + a.epsf;     // :514
+                const float vc = v < vlo ? vlo : (v > vhi ? vhi : v);
+                const bool vin = (v >= vlo) && (v <= vhi);
+                const float ec = ret - vc;
+                const float ce = ec * ec;                                     // :515
+                vterm = se > ce ? se : ce;                                    // :516
+                const float g_se = -2.0f * e, g_ce = vin ? -2.0f * ec : 0.0f;
+                if (se > ce) gvk = g_se;
+                else if (se < ce) gvk = g_ce;
+                else gvk = 0.5f * g_se + 0.5f * g_ce;                         // torch.maximum tie
+            } else {
+                vterm = se;
+                gvk = -2.0f * e;
+            }
+            gv[k] = 0.5f * gvk * invB;
+
+            const float rm1 = rho - 1.0f;
+            if (live) {
+                acc[0] += (double)m;
+                acc[1] += (double)vterm;
+                acc[2] += (fabsf(rm1) > a.epsf) ? 1.0 : 0.0;                  // :522
+                acc[3] += (double)(rm1 - logf(rho));                          // :525
+            }
+        }
+        if (a.g_x) st4(a.g_x, i, a.B, a.vec, make_float4(gx[0], gx[1], gx[2], gx[3]));
+        if (a.g_v) st4(a.g_v, i, a.B, a.vec, make_float4(gv[0], gv[1], gv[2], gv[3]));
+    }
+    block_reduce_store<4>(acc, a.partials + (size_t)blockIdx.x * 4);
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_loss_final(const double *partials, int nblocks, long B, float *out4)
+{
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += LOSS_BLOCK) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += partials[(size_t)b * 4 + k];
+    }
+    __shared__ double tot[4];
+    block_reduce_store<4>(acc, tot);
+    if (threadIdx.x == 0) {
+        const double n = (double)B;
+        out4[0] = (float)(-tot[0] / n);
+        out4[1] = (float)(0.5 * tot[1] / n);
+        out4[2] = (float)(tot[2] / n);
+        out4[3] = (float)(tot[3] / n);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ppo_loss_workspace_bytes(long B)
+{
+    (void)B;
+    return (size_t)LOSS_MAX_BLOCKS * 4 * sizeof(double);
+}
+
+int ppo_adv_stats(const float *adv, long B, double *stats3, void *workspace, size_t workspace_bytes,
+                  void *stream)
+{
+    PPO_REQUIRE(adv && stats3 && B >= 1);
+    PPO_REQUIRE(workspace && workspace_bytes >= ppo_loss_workspace_bytes(B) && ppo_aligned(workspace, 8));
+    PPO_REQUIRE(ppo_aligned(adv, 4) && ppo_aligned(stats3, 8));
+    hipStream_t s = (hipStream_t)stream;
+    double *partials = reinterpret_cast<double *>(workspace);
+    const int grid = loss_grid(B);
+    const bool vec = ppo_aligned(adv, 16);
+    hipLaunchKernelGGL(k_adv_stats_partial, dim3(grid), dim3(LOSS_BLOCK), 0, s, adv, B, partials, vec);
+    int rc = ppo_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_adv_stats_final, dim3(1), dim3(LOSS_BLOCK), 0, s, adv, B, partials, grid, stats3);
+    return ppo_launch_status();
+}
+
+int ppo_loss_fwd_bwd(const float *x, const float *old_lp, const float *new_v, const float *old_v,
+                     const float *adv, const double *stats3, double clip, int norm_adv, int clip_va,
+                     int ratio_input, long B, float *out4, float *g_x, float *g_v, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    PPO_REQUIRE(x && new_v && old_v && adv && out4 && B >= 1);
+    PPO_REQUIRE(ratio_input || old_lp);
+    PPO_REQUIRE(!norm_adv || stats3);
+    PPO_REQUIRE(workspace && workspace_bytes >= ppo_loss_workspace_bytes(B) && ppo_aligned(workspace, 8));
+    hipStream_t s = (hipStream_t)stream;
+    LossArgs a;
+    a.x = x; a.old_lp = old_lp; a.new_v = new_v; a.old_v = old_v; a.adv = adv; a.stats3 = stats3;
+    a.g_x = g_x; a.g_v = g_v; a.partials = reinterpret_cast<double *>(workspace);
+    a.lo = (float)(1.0 - clip); a.hi = (float)(1.0 + clip); a.epsf = (float)clip;
+    a.B = B; a.norm_adv = norm_adv; a.clip_va = clip_va; a.ratio_input = ratio_input;
+    a.vec = ppo_aligned(x, 16) && ppo_aligned(new_v, 16) && ppo_aligned(old_v, 16) && ppo_aligned(adv, 16) &&
+            (ratio_input || ppo_aligned(old_lp, 16)) && (!g_x || ppo_aligned(g_x, 16)) &&
+            (!g_v || ppo_aligned(g_v, 16));
+    const int grid = loss_grid(B);
+    hipLaunchKernelGGL(k_loss_partial, dim3(grid), dim3(LOSS_BLOCK), 0, s, a);
+    int rc = ppo_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(LOSS_BLOCK), 0, s, a.partials, grid, B, out4);
+    return ppo_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+"""Data-parallel glue: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on
+ROCm; "gloo" in CPU tests).
+
+The rollout and GAE shard by env with no exchange (each rank owns N/world envs; Philox
+streams are keyed by GLOBAL env id, so results do not depend on the sharding).  Only the
+update exchanges data: one flattened-gradient all-reduce per optimiser step (the dense net
+is ~5-9k parameters, i.e. a latency-bound 20-40 KB message -- bucketed into ONE collective
+rather than one per parameter), three doubles of advantage statistics when normalising, and
+the KL scalar that drives the early-stop decision (so that every rank takes the same branch).
+The reference has no distributed code at all; nothing here mirrors it.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as td
+
+
+def is_dist() -> bool:
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
+def world_size() -> int:
+    return td.get_world_size() if is_dist() else 1
+
+
+def rank() -> int:
+    return td.get_rank() if is_dist() else 0
+
+
+def init_from_env(backend: str | None = None) -> bool:
+    """Initialise from torchrun's RANK / WORLD_SIZE / MASTER_* if present."""
+    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return False
+    if td.is_initialized():
+        return True
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    td.init_process_group(backend=backend)
+    return True
+
+
+def broadcast_params(module: torch.nn.Module, src: int = 0):
+    if not is_dist():
+        return
+    flat = torch.cat([p.data.reshape(-1) for p in module.parameters()])
+    td.broadcast(flat, src)
+    off = 0
+    for p in module.parameters():
+        n = p.numel()
+        p.data.copy_(flat[off:off + n].view_as(p))
+        off += n
+
+
+def allreduce_grads(params):
+    """Mean of gradients over ranks in ONE collective (flattened bucket)."""
+    if not is_dist():
+        return
+    with_grad = [p for p in params if p.grad is not None]
+    if not with_grad:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in with_grad])
+    td.all_reduce(flat, op=td.ReduceOp.SUM)
+    flat /= world_size()
+    off = 0
+    for p in with_grad:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+
+
+def merged_adv_stats(stats3: torch.Tensor) -> torch.Tensor:
+    """All-gather {count, mean, M2} and merge (Chan et al.) so that every rank normalises its
+    minibatch with the statistics of the GLOBAL minibatch."""
+    if not is_dist():
+        return stats3
+    gathered = [torch.empty_like(stats3) for _ in range(world_size())]
+    td.all_gather(gathered, stats3)
+    from .ops import merge_stats
+    return merge_stats([(g[0], g[1], g[2]) for g in gathered])
+
+
+def mean_scalar(x: torch.Tensor) -> torch.Tensor:
+    if not is_dist():
+        return x
+    y = x.clone()
+    td.all_reduce(y, op=td.ReduceOp.SUM)
+    return y / world_size()

@@ -1,0 +1,175 @@
+"""Tensor-level wrappers over the C ABI (include/ppo_amd.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; all arithmetic on the
+hot path happens in libppo_amd.so.  Tensors that live on the CPU are staged to the HIP
+device and the result is staged back -- the computation itself never runs on the CPU, and
+with no HIP device every op raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_ws_cache: dict = {}
+
+
+def device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.PpoAmdError("ppo_amd needs a HIP device (MI355X); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
+    """Contiguous tensor of `dtype` on the HIP device (a copy only if needed)."""
+    return t.detach().to(device=device(), dtype=dtype).contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = ws
+    return ws
+
+
+# --------------------------------------------------------------------------- GAE
+def gae_dense(rewards, values, end_value_dense, done_flags, trunc_flags, gamma, lam,
+              want_returns=False, out=None, variant=None):
+    """ppo_gae_dense: replaces reference src/ppo.py:452-488 with dense bootstrap values."""
+    lib = _lib.load()
+    src_dev = rewards.device
+    r, v, ev = _dev(rewards, torch.float32), _dev(values, torch.float32), _dev(end_value_dense, torch.float32)
+    d, tr = _dev(done_flags, torch.int32), _dev(trunc_flags, torch.int32)
+    T, N = r.shape
+    assert v.shape == (T, N) and ev.shape == (T, N) and d.shape == (T, N) and tr.shape == (T, N)
+    adv = out if out is not None else torch.empty((T, N), dtype=torch.float32, device=r.device)
+    ret = torch.empty((T, N), dtype=torch.float32, device=r.device) if want_returns else None
+    if variant is None:
+        rc = lib.ppo_gae_dense(_ptr(r), _ptr(v), _ptr(ev), _ptr(d), _ptr(tr), float(gamma), float(lam),
+                               _ptr(adv), _ptr(ret), T, N, _stream())
+    else:
+        rc = lib.ppo_gae_dense_variant(_ptr(r), _ptr(v), _ptr(ev), _ptr(d), _ptr(tr), float(gamma), float(lam),
+                                       _ptr(adv), _ptr(ret), T, N, int(variant), _stream())
+    _lib.check(rc, "ppo_gae_dense")
+    if src_dev.type != "cuda":
+        adv = adv.to(src_dev)
+        ret = ret.to(src_dev) if ret is not None else None
+    return (adv, ret) if want_returns else adv
+
+
+def gae_ragged(rewards, values, end_values, done_flags, trunc_flags, gamma, lam, check_index=True):
+    """ppo_gae_ragged: exact drop-in for PPO.compute_advantages (reference src/ppo.py:452-488)."""
+    lib = _lib.load()
+    src_dev = rewards.device
+    r, v, ev = _dev(rewards, torch.float32), _dev(values, torch.float32), _dev(end_values, torch.float32)
+    d, tr = _dev(done_flags, torch.int32), _dev(trunc_flags, torch.int32)
+    T, N = r.shape
+    assert v.shape == (T, N) and d.shape == (T, N) and tr.shape == (T, N) and ev.dim() == 1
+    adv = torch.empty((T, N), dtype=torch.float32, device=r.device)
+    nws = lib.ppo_gae_ragged_workspace_bytes(N)
+    ws = torch.empty(max(nws, 8), dtype=torch.uint8, device=r.device)
+    err = torch.zeros(1, dtype=torch.int32, device=r.device)
+    rc = lib.ppo_gae_ragged(_ptr(r), _ptr(v), _ptr(ev), ev.numel(), _ptr(d), _ptr(tr), float(gamma), float(lam),
+                            _ptr(adv), T, N, _ptr(ws), ws.numel(), _ptr(err), _stream())
+    _lib.check(rc, "ppo_gae_ragged")
+    if check_index and int(err.item()) != 0:  # torch raises IndexError at src/ppo.py:478
+        raise IndexError("index out of range in end_values (done+trunc bookkeeping does not match end_values)")
+    return adv if src_dev.type == "cuda" else adv.to(src_dev)
+
+
+# --------------------------------------------------------------------------- loss
+def adv_stats(adv: torch.Tensor) -> torch.Tensor:
+    """{count, mean, M2} (fp64, device) of a flat advantage tensor (reference src/ppo.py:501)."""
+    lib = _lib.load()
+    a = _dev(adv, torch.float32).reshape(-1)
+    stats = torch.empty(3, dtype=torch.float64, device=a.device)
+    ws = _workspace(lib.ppo_loss_workspace_bytes(a.numel()), a.device)
+    _lib.check(lib.ppo_adv_stats(_ptr(a), a.numel(), _ptr(stats), _ptr(ws), ws.numel(), _stream()),
+               "ppo_adv_stats")
+    return stats
+
+
+def merge_stats(stats_list):
+    """Chan et al. merge of {count, mean, M2} triples (data-parallel ranks)."""
+    n, mean, m2 = stats_list[0]
+    for nb, mb, m2b in stats_list[1:]:
+        tot = n + nb
+        delta = mb - mean
+        mean = mean + delta * nb / tot
+        m2 = m2 + m2b + delta * delta * n * nb / tot
+        n = tot
+    return torch.stack([n, mean, m2])
+
+
+def loss_fwd_bwd(x, old_lp, new_v, old_v, adv, clip, norm_adv, clip_va, ratio_input, stats3=None,
+                 want_grads=True):
+    """ppo_loss_fwd_bwd: returns (out4 [device f32x4], g_x, g_v)."""
+    lib = _lib.load()
+    x_, nv, ov, a = (_dev(t, torch.float32).reshape(-1) for t in (x, new_v, old_v, adv))
+    olp = None if old_lp is None else _dev(old_lp, torch.float32).reshape(-1)
+    B = x_.numel()
+    assert nv.numel() == B and ov.numel() == B and a.numel() == B
+    if norm_adv and stats3 is None:
+        stats3 = adv_stats(a)
+    out4 = torch.empty(4, dtype=torch.float32, device=x_.device)
+    g_x = torch.empty(B, dtype=torch.float32, device=x_.device) if want_grads else None
+    g_v = torch.empty(B, dtype=torch.float32, device=x_.device) if want_grads else None
+    ws = _workspace(lib.ppo_loss_workspace_bytes(B), x_.device)
+    rc = lib.ppo_loss_fwd_bwd(_ptr(x_), _ptr(olp), _ptr(nv), _ptr(ov), _ptr(a), _ptr(stats3), float(clip),
+                              int(bool(norm_adv)), int(bool(clip_va)), int(bool(ratio_input)), B,
+                              _ptr(out4), _ptr(g_x), _ptr(g_v), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "ppo_loss_fwd_bwd")
+    return out4, g_x, g_v
+
+
+class _PPOLossFn(torch.autograd.Function):
+    """Autograd node around ppo_loss_fwd_bwd.  The kernel produces both losses and both
+    per-sample gradients in one pass; backward only scales them by the upstream scalars."""
+
+    @staticmethod
+    def forward(ctx, x, new_v, old_lp, old_v, adv, clip, norm_adv, clip_va, ratio_input, stats3):
+        out4, g_x, g_v = loss_fwd_bwd(x, old_lp, new_v, old_v, adv, clip, norm_adv, clip_va, ratio_input,
+                                      stats3=stats3, want_grads=True)
+        ctx.save_for_backward(g_x, g_v)
+        ctx.x_meta = (x.shape, x.device)
+        ctx.v_meta = (new_v.shape, new_v.device)
+        o = out4.to(x.device)
+        pl, vl, cf, kl = o[0], o[1], o[2], o[3]
+        ctx.mark_non_differentiable(cf, kl)
+        return pl, vl, cf, kl
+
+    @staticmethod
+    def backward(ctx, g_pl, g_vl, _g_cf, _g_kl):
+        g_x, g_v = ctx.saved_tensors
+        (xs, xd), (vs, vd) = ctx.x_meta, ctx.v_meta
+        gx = (g_x * g_pl.to(g_x.device)).to(xd).reshape(xs) if ctx.needs_input_grad[0] else None
+        gv = (g_v * g_vl.to(g_v.device)).to(vd).reshape(vs) if ctx.needs_input_grad[1] else None
+        return gx, gv, None, None, None, None, None, None, None, None
+
+
+def ppo_losses(x, new_v, old_lp, old_v, adv, clip, norm_adv, clip_va, ratio_input, stats3=None):
+    """Differentiable (policy_loss, value_loss, clip_frac, kl_div), each 0-d f32."""
+    return _PPOLossFn.apply(x, new_v, old_lp, old_v, adv, float(clip), bool(norm_adv), bool(clip_va),
+                            bool(ratio_input), stats3)
+
+
+# --------------------------------------------------------------------------- sampling
+def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int, action_out=None, logp_out=None):
+    lib = _lib.load()
+    lg = _dev(logits, torch.float32)
+    N, A = lg.shape
+    action = action_out if action_out is not None else torch.empty(N, dtype=torch.int32, device=lg.device)
+    logp = logp_out if logp_out is not None else torch.empty(N, dtype=torch.float32, device=lg.device)
+    rc = lib.ppo_categorical_sample(_ptr(lg), A, seed, env_base, step, _ptr(action), _ptr(logp), N, _stream())
+    _lib.check(rc, "ppo_categorical_sample")
+    return action, logp

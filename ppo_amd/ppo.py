@@ -1,0 +1,570 @@
+"""Python surface of the MI355X-native PPO path: ScaledBeta, Agent, SyncVecEnv, PPO.
+
+Same class / method / attribute names and argument meaning as the reference's src/ppo.py
+(cited per item), written from scratch around libppo_amd.so:
+
+* env stepping, auto-reset, terminal-obs capture, episode statistics  -> ppo_env_step
+* GAE(lambda)                                                          -> ppo_gae_dense / _ragged
+* ratio + clipped surrogate + value loss + their gradients            -> ppo_loss_fwd_bwd
+* the small policy/value MLP (and the Atari CNN) stay on PyTorch-ROCm (north star).
+
+Out of scope on purpose: GIF rendering, wandb.  The flags are
+accepted; metrics keep the reference's names and go to `PPO.last_metrics` (+ a JSONL file
+when PPO_AMD_METRICS is set).
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Callable
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import dist as ppo_dist
+from . import envs as ppo_envs
+from . import ops, spaces
+
+try:  # optional, never required
+    import tqdm as _tqdm
+except Exception:  # pragma: no cover
+    _tqdm = None
+
+
+# ----------------------------------------------------------------------------------------
+class ScaledBeta(torch.distributions.Distribution):
+    """Beta on [low, high] parameterised by mode and precision (reference src/ppo.py:18-56):
+    alpha = mode * precision + 1, beta = precision + 2 - alpha; log-prob and entropy are
+    summed over the action dimension."""
+
+    def __init__(self, modes, precisions, lows, highs):
+        super().__init__(validate_args=False)
+        self.modes, self.precisions, self.lows, self.highs = modes, precisions, lows, highs
+        self.alphas = modes * precisions + 1.0
+        self.betas = precisions + 2.0 - self.alphas
+        self.diffs = highs - lows
+        self.log_diffs = torch.log(self.diffs)
+        self.epsilon = 1e-6
+        self.unit_beta_dist = torch.distributions.Beta(self.alphas, self.betas)
+
+    def sample(self):
+        return self.unit_beta_dist.sample() * self.diffs + self.lows
+
+    def log_prob(self, variates):
+        unit = (variates - self.lows) / (self.diffs + self.epsilon)
+        return torch.sum(self.unit_beta_dist.log_prob(unit) - self.log_diffs, dim=1)
+
+    def entropy(self):
+        return torch.sum(self.unit_beta_dist.entropy() + self.log_diffs, dim=1)
+
+
+# ----------------------------------------------------------------------------------------
+def _ortho(layer, std=float(np.sqrt(2))):
+    nn.init.orthogonal_(layer.weight, std)  # reference src/ppo.py:87-89 (bias keeps torch default)
+    return layer
+
+
+class Agent(nn.Module):
+    """Policy/value network with the reference's architecture and init (src/ppo.py:58-216):
+    dense 64-64 tanh (or Nature-CNN -> 512) backbone(s), policy head gain 0.01, critic gain 1."""
+
+    def __init__(self, state_space, action_space, conv_net, joint_net, device):
+        super().__init__()
+        self.action_space, self.state_space = action_space, state_space
+        self.conv_net, self.joint_net = conv_net, joint_net
+        self.discrete = spaces.is_discrete(action_space)
+        if not self.discrete and not spaces.is_box(action_space):
+            raise TypeError("action_space must be Discrete-like (.n) or Box-like (.low/.high/.shape)")
+        self.image_states = len(state_space.shape) >= 3
+        n_out = action_space.n if self.discrete else 2 * action_space.shape[0]
+        width = 512 if conv_net else 64
+        self.pi_backbone = self._backbone()
+        if not joint_net:
+            self.va_backbone = self._backbone()
+        self.policy = _ortho(nn.Linear(width, n_out), 0.01)
+        self.critic = _ortho(nn.Linear(width, 1), 1.0)
+        self.device = device
+        self.to(self.device, dtype=torch.float32)
+        self._bounds = None
+
+    def _backbone(self):
+        shape = self.state_space.shape
+        if self.conv_net:  # reference src/ppo.py:93-103
+            return nn.Sequential(
+                _ortho(nn.Conv2d(shape[-1], 32, 8, stride=4)), nn.ReLU(),
+                _ortho(nn.Conv2d(32, 64, 4, stride=2)), nn.ReLU(),
+                _ortho(nn.Conv2d(64, 64, 3, stride=1)), nn.ReLU(),
+                nn.Flatten(),
+                _ortho(nn.Linear(64 * 7 * 7, 512)), nn.ReLU())
+        return nn.Sequential(  # reference src/ppo.py:126-131
+            _ortho(nn.Linear(shape[0], 64)), nn.Tanh(),
+            _ortho(nn.Linear(64, 64)), nn.Tanh())
+
+    def permute_states(self, states):
+        return torch.permute(states, (0, 3, 1, 2))  # NHWC -> NCHW, reference src/ppo.py:147-148
+
+    def _prep(self, states):
+        return self.permute_states(states) if self.image_states else states
+
+    def get_values(self, states):
+        """reference src/ppo.py:150-164"""
+        states = self._prep(states)
+        hidden = self.pi_backbone(states) if self.joint_net else self.va_backbone(states)
+        return torch.flatten(self.critic(hidden))
+
+    def policy_and_values(self, states):
+        """Raw policy head output [B, n_out] and values [B] (first half of
+        get_actions_and_values, reference src/ppo.py:172-182)."""
+        states = self._prep(states)
+        pi_hidden = self.pi_backbone(states)
+        va_hidden = pi_hidden if self.joint_net else self.va_backbone(states)
+        return self.policy(pi_hidden), self.critic(va_hidden).flatten()
+
+    def _action_bounds(self, device):
+        if self._bounds is None or self._bounds[0].device != device:
+            n = self.action_space.shape[0]
+            lows, highs = self.action_space.low, self.action_space.high
+            if not isinstance(lows, np.ndarray):  # scalar bounds, reference src/ppo.py:196-198
+                lows = lows * np.ones((n,), dtype=np.float32)
+                highs = highs * np.ones((n,), dtype=np.float32)
+            self._bounds = (torch.tensor(lows, device=device), torch.tensor(highs, device=device))
+        return self._bounds
+
+    def distribution(self, policy_output):
+        if self.discrete:
+            return torch.distributions.Categorical(logits=policy_output)
+        n = self.action_space.shape[0]
+        lows, highs = self._action_bounds(policy_output.device)
+        modes = 0.5 * (torch.clip(policy_output[:, :n], min=-1.0, max=1.0) + 1)  # reference :204
+        precisions = torch.exp(policy_output[:, n:])                              # reference :205
+        return ScaledBeta(modes, precisions, lows, highs)
+
+    def get_actions_and_values(self, states, actions):
+        """reference src/ppo.py:166-216 -> (actions, log_probs, values, mean entropy)"""
+        policy_output, values = self.policy_and_values(states)
+        dist = self.distribution(policy_output)
+        if actions is None:
+            actions = dist.sample().to(dtype=torch.int32 if self.discrete else torch.float32)
+        return actions, dist.log_prob(actions), values, dist.entropy().mean()
+
+
+# ----------------------------------------------------------------------------------------
+class SyncVecEnv:
+    """Vectorised env + rollout collector with the reference's contract (src/ppo.py:218-417).
+
+    If `env_fn()` yields a ppo_amd.envs.DeviceEnv (CartPole / Acrobot) all `num_envs` envs
+    live in HBM and one ppo_env_step launch per time step does stepping, flags, forced
+    last-step truncation, terminal-obs capture, auto-reset and episode statistics.  Any
+    other gym.Env-protocol object keeps its own host stepping (Breakout / Galaxian / Ant in
+    the reference) and only GAE and the loss run on the GPU kernels.
+    """
+
+    def __init__(self, env_fn: Callable, num_envs: int, steps_per_env: int, render_every: int,
+                 render_fps: float, agent: Agent, seed: int | None = None, env_base: int = 0):
+        self.num_envs, self.steps_per_env = num_envs, steps_per_env
+        self.global_steps = 0
+        self.can_record = render_every > 0
+        if self.can_record:
+            print("ppo_amd: GIF rendering is out of scope for device-resident envs; render_every ignored")
+        self.render_every, self.render_fps = (render_every if render_every > 0 else 1), render_fps
+        self.agent = agent
+        nan = np.float32(np.nan)
+        self.max_ep_return = self.lower_ep_return = self.median_ep_return = nan
+        self.upper_ep_return = self.median_ep_length = nan
+        self.state_space, self.action_space = agent.state_space, agent.action_space
+        self.action_dtype = torch.int32 if spaces.is_discrete(self.action_space) else torch.float32
+        self.device = agent.device
+        self.fused_sampling = True  # device path: Categorical sample + log_prob in one kernel
+        self._rollouts = 0
+
+        first = env_fn()
+        self.native = isinstance(first, ppo_envs.DeviceEnv)
+        if self.native:
+            self.batch = ppo_envs.DeviceEnvBatch(first.kind, num_envs, seed=seed if seed is not None else first.seed,
+                                                 env_base=env_base)
+            self.kdev = self.batch.device           # where the env kernels run (always HIP)
+            self.envs = [first]
+            self._term_obs = None
+            self._ev_dense = None
+        else:
+            self.batch, self.kdev = None, None
+            self.envs = [first] + [env_fn() for _ in range(num_envs - 1)]
+        self.t_states = self.vec_reset()
+
+    def close(self):
+        self.envs = None
+        self.batch = None
+
+    # -- reset / step ---------------------------------------------------------------------
+    def vec_reset(self) -> torch.Tensor:
+        """reference src/ppo.py:269-275"""
+        if self.native:
+            return self.batch.reset().to(self.device)
+        states = torch.zeros((self.num_envs, *self.state_space.shape), dtype=torch.float32, device=self.device)
+        for i, env in enumerate(self.envs):
+            states[i] = torch.as_tensor(np.asarray(env.reset()[0]), dtype=torch.float32)
+        return states
+
+    def env_reset(self, env_id: int):
+        """reference src/ppo.py:277-281 (host envs only: device envs reset inside the step kernel)"""
+        if self.native:
+            raise RuntimeError("device-resident envs auto-reset inside ppo_env_step; env_reset is host-path only")
+        return torch.as_tensor(np.asarray(self.envs[env_id].reset()[0]), dtype=torch.float32, device=self.device)
+
+    def vec_step(self, actions: torch.Tensor):
+        """reference src/ppo.py:283-302 -> (states, rewards, done_flags i32, trunc_flags i32).
+        Device envs: the returned states are the NEXT observations, i.e. already the reset
+        observation for envs that finished (the reference does that two lines later, :381-382)."""
+        N = self.num_envs
+        if self.native:
+            d = self.kdev
+            obs = torch.empty((N, self.batch.obs_dim), dtype=torch.float32, device=d)
+            rew = torch.empty(N, dtype=torch.float32, device=d)
+            done = torch.empty(N, dtype=torch.int32, device=d)
+            trunc = torch.empty(N, dtype=torch.int32, device=d)
+            act = actions.to(d, torch.int32).contiguous()
+            self.batch.step(act, obs, None, rew, done, trunc, is_last=False)
+            return tuple(x.to(self.device) for x in (obs, rew, done, trunc))
+        acts = actions.cpu().numpy()
+        states = np.zeros((N, *self.state_space.shape), dtype=np.float32)
+        rewards = np.zeros(N, dtype=np.float32)
+        dones = np.zeros(N, dtype=np.int32)
+        truncs = np.zeros(N, dtype=np.int32)
+        for i, env in enumerate(self.envs):
+            states[i], rewards[i], dones[i], truncs[i], _ = env.step(np.squeeze(acts[i]))
+        dev = self.device
+        return (torch.from_numpy(states).to(dev), torch.from_numpy(rewards).to(dev),
+                torch.from_numpy(dones).to(dev), torch.from_numpy(truncs).to(dev))
+
+    # -- rollout --------------------------------------------------------------------------
+    def _alloc(self, dev):
+        T, N = self.steps_per_env, self.num_envs
+        self.states = torch.empty((T, N, *self.state_space.shape), dtype=torch.float32, device=dev)
+        self.actions = torch.empty((T, N, *self.action_space.shape), dtype=self.action_dtype, device=dev)
+        self.rewards = torch.empty((T, N), dtype=torch.float32, device=dev)
+        self.done_flags = torch.empty((T, N), dtype=torch.int32, device=dev)
+        self.trunc_flags = torch.empty((T, N), dtype=torch.int32, device=dev)
+        self.values = torch.empty((T, N), dtype=torch.float32, device=dev)
+        self.log_probs = torch.empty((T, N), dtype=torch.float32, device=dev)
+
+    def rollout(self):
+        """reference src/ppo.py:304-417"""
+        with torch.no_grad():
+            if self.native:
+                self._rollout_device()
+            else:
+                self._rollout_host()
+        self._rollouts += 1
+        self.states.requires_grad = True  # reference src/ppo.py:400
+
+    def _rollout_device(self):
+        T, N, b = self.steps_per_env, self.num_envs, self.batch
+        kdev, adev = self.kdev, torch.device(self.device)
+        same = adev.type == "cuda"
+        self._alloc(kdev)
+        if self._term_obs is None or self._term_obs.shape[0] != T:
+            self._term_obs = torch.empty((T, N, b.obs_dim), dtype=torch.float32, device=kdev)
+        carry = torch.empty((N, b.obs_dim), dtype=torch.float32, device=kdev)
+        self.states[0].copy_(self.t_states)
+        fused = self.fused_sampling and same and self.agent.discrete
+        for t in range(T):
+            obs = self.states[t] if same else self.states[t].to(adev)
+            if fused:
+                logits, values = self.agent.policy_and_values(obs)
+                ops.categorical_sample(logits, b.seed, b.env_base, self._rollouts * T + t,
+                                       action_out=self.actions[t], logp_out=self.log_probs[t])
+                self.values[t].copy_(values)
+            else:
+                a, lp, v, _ = self.agent.get_actions_and_values(obs, actions=None)
+                self.actions[t].copy_(a)
+                self.log_probs[t].copy_(lp)
+                self.values[t].copy_(v)
+            nxt = self.states[t + 1] if t + 1 < T else carry
+            b.step(self.actions[t], nxt, self._term_obs[t], self.rewards[t], self.done_flags[t],
+                   self.trunc_flags[t], is_last=(t == T - 1))
+        self.global_steps += T * N
+        self.t_states = carry if same else carry.to(adev)
+
+        # end_states: terminal observations, actor-major / time-ascending (reference :401-402)
+        ended = (self.done_flags + self.trunc_flags) > 0
+        nt = ended.t().nonzero()                       # one host sync per rollout (size E)
+        self._end_n, self._end_t = nt[:, 0], nt[:, 1]
+        self.end_states = self._term_obs[self._end_t, self._end_n]
+        self.total_return = np.float32(self.rewards.sum(dtype=torch.float32).item())
+        if not same:
+            for name in ("states", "actions", "rewards", "done_flags", "trunc_flags", "values", "log_probs",
+                         "end_states"):
+                setattr(self, name, getattr(self, name).to(adev))
+        self._episode_percentiles(*b.episode_stats())
+
+    def _rollout_host(self):
+        """Host-stepped gym envs; the control flow of reference src/ppo.py:320-398 with the
+        per-actor bookkeeping done on whole [N] arrays."""
+        T, N, dev = self.steps_per_env, self.num_envs, self.device
+        self._alloc(dev)
+        end_states = [[] for _ in range(N)]
+        total = np.float32(0.0)
+        for t in range(T):
+            a, lp, v, _ = self.agent.get_actions_and_values(self.t_states, actions=None)
+            new_states, rewards, dones, truncs = self.vec_step(a)
+            d_np, tr_np = dones.cpu().numpy(), truncs.cpu().numpy().copy()
+            for r in rewards.cpu().numpy():
+                total = np.float32(total + r)          # reference :348 accumulates in np.float32
+            new_states = new_states.clone()
+            for n in range(N):
+                ended = d_np[n] + tr_np[n]
+                can_reset = True
+                if ended == 0 and t == T - 1:          # reference :353-356
+                    ended, can_reset = 1, False
+                    tr_np[n] += 1
+                if ended > 0:                          # reference :377-382
+                    end_states[n].append(new_states[n].cpu().clone())
+                    if can_reset:
+                        new_states[n] = self.env_reset(n)
+            self.global_steps += N
+            self.states[t], self.actions[t], self.rewards[t] = self.t_states, a, rewards
+            self.done_flags[t] = dones
+            self.trunc_flags[t] = torch.from_numpy(tr_np).to(dev)
+            self.values[t], self.log_probs[t] = v, lp
+            self.t_states = new_states
+        self.total_return = total
+        self.end_states = torch.cat([torch.stack(e, dim=0) for e in end_states], dim=0).to(dev)
+        self._end_n = self._end_t = None
+        if not hasattr(self.envs[0], "return_queue"):  # reference :404-405
+            return
+        rets = np.concatenate([np.array(e.return_queue, dtype=np.float64).reshape(-1) for e in self.envs])
+        lens = np.concatenate([np.array(e.length_queue, dtype=np.float64).reshape(-1) for e in self.envs])
+        self._episode_percentiles(torch.from_numpy(rets), torch.from_numpy(lens))
+
+    def _episode_percentiles(self, rets: torch.Tensor, lens: torch.Tensor):
+        """reference src/ppo.py:407-417: running max, 5/50/95 percentiles (linear), median length"""
+        if rets.numel() > 0:
+            srt = torch.sort(rets.to(torch.float64)).values
+            q = _percentiles(srt, (5.0, 50.0, 95.0)).cpu().numpy()
+            mx = np.float32(srt[-1].item())
+            if np.isnan(self.max_ep_return) or mx > self.max_ep_return:
+                self.max_ep_return = mx
+            self.lower_ep_return, self.median_ep_return, self.upper_ep_return = (np.float64(x) for x in q)
+        if lens.numel() > 0:
+            srt = torch.sort(lens.to(torch.float64)).values
+            self.median_ep_length = np.float64(_percentiles(srt, (50.0,)).item())
+
+
+def _percentiles(sorted_vals: torch.Tensor, qs) -> torch.Tensor:
+    """np.percentile(..., method='linear') on an ascending 1-d tensor."""
+    n = sorted_vals.numel()
+    pos = torch.tensor(qs, dtype=torch.float64, device=sorted_vals.device) / 100.0 * (n - 1)
+    lo = pos.floor().long()
+    hi = torch.clamp(lo + 1, max=n - 1)
+    frac = pos - lo.to(torch.float64)
+    return sorted_vals[lo] + (sorted_vals[hi] - sorted_vals[lo]) * frac
+
+
+# ----------------------------------------------------------------------------------------
+class PPO:
+    """PPO trainer with the reference's constructor, methods and metrics (src/ppo.py:420-763)."""
+
+    def __init__(self, discount_factor, gae_factor, norm_adv, clip_va_loss, conv_net, joint_network,
+                 use_gpu, **kwargs):
+        self.discount_factor, self.gae_factor = discount_factor, gae_factor
+        self.norm_adv, self.clip_va_loss = norm_adv, clip_va_loss
+        self.conv_net, self.joint_network, self.use_gpu = conv_net, joint_network, use_gpu
+        self.project_name = kwargs.get("project_name", None)
+        self.seed = kwargs.get("seed", None)
+        self.agent: Agent = None
+        self.vec_env: SyncVecEnv = None
+        self.pi_optimizer = None
+        self.va_optimizer = None
+        # where the MLP and the rollout buffers live; the kernels always run on the HIP device
+        self.device = "cuda" if (use_gpu and torch.cuda.is_available()) else "cpu"
+        self.updates = 0
+        self.last_metrics: dict = {}
+
+    # -- hot path: GAE --------------------------------------------------------------------
+    def compute_advantages(self, rewards, values, end_values, done_flags, trunc_flags):
+        """reference src/ppo.py:452-488 -> [T, N] f32 on self.device (ppo_gae_ragged)."""
+        adv = ops.gae_ragged(rewards, values, end_values, done_flags, trunc_flags,
+                             self.discount_factor, self.gae_factor)
+        return adv.to(self.device)
+
+    # -- hot path: loss -------------------------------------------------------------------
+    def compute_losses(self, prob_ratios, curr_values, prev_values, advantages, clip_ratio):
+        """reference src/ppo.py:490-527 -> (policy_loss, value_loss, clip_frac, kl_div), 0-d f32;
+        the first two carry gradients to prob_ratios / curr_values (ppo_loss_fwd_bwd)."""
+        return ops.ppo_losses(prob_ratios, curr_values, None, prev_values, advantages, clip_ratio,
+                              self.norm_adv, self.clip_va_loss, ratio_input=True)
+
+    # -- one update -----------------------------------------------------------------------
+    def train_step(self, num_epochs, batch_size, critic_coef, entropy_coef, clip_ratio, target_div,
+                   max_grad_norm, lr_anneal):
+        """reference src/ppo.py:529-673"""
+        ve = self.vec_env
+        num_envs, steps_per_env = ve.num_envs, ve.steps_per_env
+        world = ppo_dist.world_size()
+
+        rollout_start = time.time()
+        ve.rollout()
+        with torch.no_grad():
+            end_values = self.agent.get_values(ve.end_states)
+            advantages = self._advantages(ve, end_values)
+        _sync()
+        rollout_time = time.time() - rollout_start
+        env_steps_per_sec = steps_per_env * num_envs * world / rollout_time
+
+        states = ve.states.detach().flatten(0, 1)  # no gradient wrt observations is ever used
+        actions = ve.actions.flatten(0, 1)
+        log_probs = ve.log_probs.flatten(0, 1)
+        values = ve.values.flatten(0, 1)
+        advantages = advantages.flatten(0, 1)
+        data_size = steps_per_env * num_envs
+        dev = states.device
+
+        updates_start = time.time()
+        early = torch.zeros((), dtype=torch.bool, device=dev)
+        clip_sum = torch.zeros((), dtype=torch.float32, device=dev)
+        grad_steps_done = 0
+        params = [p for p in self.agent.parameters()]
+        for _epoch in range(num_epochs):
+            perm = torch.randperm(data_size, device=dev)       # reference :575-576 (np.random.shuffle)
+            for start in range(0, data_size, batch_size):
+                idx = perm[start:start + batch_size]           # last minibatch may be short (:581)
+                mb_states, mb_actions = states[idx], actions[idx]
+                mb_log_probs, mb_values, mb_adv = log_probs[idx], values[idx], advantages[idx]
+                _, new_log_probs, new_values, entropy = self.agent.get_actions_and_values(mb_states, mb_actions)
+                stats3 = None
+                if self.norm_adv and world > 1:                # keep minibatch normalisation global
+                    stats3 = ppo_dist.merged_adv_stats(ops.adv_stats(mb_adv))
+                policy_loss, critic_loss, clip_frac, kl_div = ops.ppo_losses(
+                    new_log_probs, new_values, mb_log_probs, mb_values, mb_adv, clip_ratio,
+                    self.norm_adv, self.clip_va_loss, ratio_input=False, stats3=stats3)  # :595-599
+                if self.joint_network:                         # reference :602-609
+                    total = (policy_loss + critic_coef * critic_loss - entropy_coef * entropy) * lr_anneal
+                    self.pi_optimizer.zero_grad()
+                    total.backward()
+                    ppo_dist.allreduce_grads(params)
+                    nn.utils.clip_grad_norm_(params, max_grad_norm)
+                    self.pi_optimizer.step()
+                else:                                          # reference :610-625
+                    full_policy = (policy_loss - entropy_coef * entropy) * lr_anneal
+                    self.pi_optimizer.zero_grad()
+                    full_policy.backward(retain_graph=True)
+                    ppo_dist.allreduce_grads(params)
+                    nn.utils.clip_grad_norm_(params, max_grad_norm)
+                    self.pi_optimizer.step()
+                    critic_loss = critic_coef * critic_loss
+                    self.va_optimizer.zero_grad()
+                    (critic_loss * lr_anneal).backward()
+                    ppo_dist.allreduce_grads(params)
+                    nn.utils.clip_grad_norm_(params, max_grad_norm)
+                    self.va_optimizer.step()
+                if target_div is not None:                     # reference :628-629
+                    kl_all = ppo_dist.mean_scalar(kl_div.detach())
+                    early = early | (kl_all > target_div).to(dev)
+                clip_sum += clip_frac.detach().to(dev)
+                grad_steps_done += 1
+            if target_div is not None and bool(early.item()):  # checked at the end of an epoch (:634)
+                break
+        _sync()
+        updates_time = time.time() - updates_start
+        grad_steps_per_sec = grad_steps_done / updates_time
+        global_steps_per_sec = steps_per_env * num_envs * world / (rollout_time + updates_time)
+
+        policy_loss, critic_loss = policy_loss.item(), critic_loss.item()
+        entropy, kl_div = entropy.item(), kl_div.item()
+        clip_frac = float(clip_sum.item() / max(grad_steps_done, 1))
+        rollout_return = float(ve.total_return) / num_envs
+        ep_return_max = float(ve.max_ep_return)
+        self.last_metrics = {  # reference :656-670, same names
+            "utils/ep_return_0.50": float(ve.median_ep_return),
+            "utils/ep_return_0.05": float(ve.lower_ep_return),
+            "utils/ep_return_0.95": float(ve.upper_ep_return),
+            "utils/env_steps_per_sec": env_steps_per_sec,
+            "utils/grad_steps_per_sec": grad_steps_per_sec,
+            "utils/global_steps_per_sec": global_steps_per_sec,
+            "losses/policy_loss": policy_loss,
+            "losses/critic_loss": critic_loss,
+            "losses/entropy": entropy,
+            "metrics/clip_frac": clip_frac,
+            "metrics/kl_div": kl_div,
+            "metrics/roll_return": rollout_return,
+            "metrics/ep_return_max": ep_return_max,
+            "metrics/ep_length_0.50": float(ve.median_ep_length),
+        }
+        self._log(self.last_metrics, step=self.updates * steps_per_env * num_envs * world)
+        return policy_loss, critic_loss, entropy, clip_frac, kl_div, rollout_return, ep_return_max
+
+    def _scatter_end_values(self, ve: SyncVecEnv, end_values: torch.Tensor) -> torch.Tensor:
+        """Dense bootstrap buffer: V(terminal obs) written at the (t, n) that raised the flag.  Only
+        those cells are ever read by ppo_gae_dense, so the buffer is reused without clearing."""
+        if ve._ev_dense is None or ve._ev_dense.shape != ve.rewards.shape:
+            ve._ev_dense = torch.empty_like(ve.rewards)
+        ve._ev_dense[ve._end_t, ve._end_n] = end_values
+        return ve._ev_dense
+
+    def _advantages(self, ve: SyncVecEnv, end_values: torch.Tensor) -> torch.Tensor:
+        if ve.native and ve._end_t is not None and ve.rewards.device.type == "cuda":
+            ev_dense = self._scatter_end_values(ve, end_values)
+            return ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags,
+                                 self.discount_factor, self.gae_factor)
+        return self.compute_advantages(ve.rewards, ve.values, end_values, ve.done_flags, ve.trunc_flags)
+
+    def _log(self, metrics: dict, step: int):
+        path = os.environ.get("PPO_AMD_METRICS")
+        if path and ppo_dist.rank() == 0:
+            with open(path, "a") as f:
+                f.write(json.dumps({"step": step, **metrics}) + "\n")
+
+    # -- training loop ----------------------------------------------------------------------
+    def train(self, env_fn, num_updates, num_envs, steps_per_env, num_epochs, batch_size, critic_coef,
+              entropy_coef, clip_ratio, max_grad_norm, learning_rate, target_div=None, render_every=0,
+              render_fps=0.0, early_stop_reward=None):
+        """reference src/ppo.py:675-763.  Under torch.distributed (one process per GPU) `num_envs`
+        is the GLOBAL env count; every rank owns num_envs / world_size of them."""
+        test_env = env_fn()
+        test_obs_shape = np.asarray(test_env.reset()[0]).shape
+        state_space = test_env.observation_space
+        if hasattr(state_space, "_shape") and test_obs_shape != state_space.shape:
+            state_space._shape = test_obs_shape            # reference :722-723
+        action_space = test_env.action_space
+        del test_env
+
+        world, rank = ppo_dist.world_size(), ppo_dist.rank()
+        if num_envs % world != 0:
+            raise ValueError(f"num_envs={num_envs} must be divisible by world_size={world}")
+        local_envs = num_envs // world
+        self.agent = Agent(state_space, action_space, conv_net=self.conv_net, joint_net=self.joint_network,
+                           device=self.device)
+        ppo_dist.broadcast_params(self.agent)
+        self.vec_env = SyncVecEnv(env_fn, local_envs, steps_per_env, render_every, render_fps, self.agent,
+                                  seed=self.seed, env_base=rank * local_envs)
+        # both optimisers cover ALL parameters, as in the reference (:732-733)
+        self.pi_optimizer = optim.Adam(self.agent.parameters(), lr=learning_rate, eps=1e-5)
+        self.va_optimizer = optim.Adam(self.agent.parameters(), lr=learning_rate, eps=1e-5)
+        lr_anneal = 1.0
+
+        it = range(num_updates)
+        pbar = _tqdm.trange(num_updates, leave=True) if (_tqdm is not None and rank == 0) else None
+        for _update in (pbar if pbar is not None else it):
+            pi_loss, va_loss, entropy, clip_frac, kl_div, roll_return, ep_return_max = self.train_step(
+                num_epochs, batch_size, critic_coef, entropy_coef, clip_ratio, target_div, max_grad_norm, lr_anneal)
+            if num_updates > 1:                            # the reference divides by zero here for 1 update (:748)
+                lr_anneal -= 0.999 / (num_updates - 1)
+            self.updates += 1
+            if pbar is not None:
+                pbar.set_postfix({"pi_loss": f"{pi_loss:.3f}", "va_loss": f"{va_loss:.3f}",
+                                  "entropy": f"{entropy:.3f}", "return": f"{roll_return:.3f}",
+                                  "max_ep_ret": f"{ep_return_max:.3f}", "kl_div": f"{kl_div:.4f}",
+                                  "clip_frac": f"{clip_frac:.3f}"})
+            if early_stop_reward is not None and ep_return_max >= early_stop_reward:
+                if pbar is not None:
+                    pbar.close()
+                print("Early stop reward reached.")
+                break
+
+
+def _sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()

@@ -1,0 +1,189 @@
+"""GPU parity: ppo_env_reset / ppo_env_step (through the C ABI) vs the CPU oracle
+(oracle/ppo_oracle.c, physics PARITY UNPINNED at the gymnasium boundary -- see its header).
+
+Bar: done / trunc flags, TimeLimit counters, episode lengths and reset counters BIT-EXACT;
+fp64 state and f32 observations within 1e-5 relative (measured: a few ulp -- only the device
+sin/cos differ from glibc's).  Philox reset draws are integer arithmetic: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+class DevBatch:
+    """Thin driver around ppo_amd.envs.DeviceEnvBatch mirroring oracle.cref.BatchEnv.step."""
+
+    def __init__(self, kind, N, seed=0, env_base=0):
+        from ppo_amd.envs import DeviceEnvBatch
+        self.b = DeviceEnvBatch(kind, N, seed=seed, env_base=env_base)
+        d, od = self.b.device, self.b.obs_dim
+        self.obs = torch.empty((N, od), dtype=torch.float32, device=d)
+        self.term = torch.zeros((N, od), dtype=torch.float32, device=d)
+        self.rew = torch.empty(N, dtype=torch.float32, device=d)
+        self.done = torch.empty(N, dtype=torch.int32, device=d)
+        self.trunc = torch.empty(N, dtype=torch.int32, device=d)
+
+    def reset(self, reset_draw=None):
+        rd = None if reset_draw is None else torch.from_numpy(np.asarray(reset_draw, np.float64)).cuda()
+        return self.b.reset(self.obs, rd).cpu().numpy()
+
+    def step(self, action, is_last=False, reset_draw=None):
+        a = torch.from_numpy(np.asarray(action, np.int32)).cuda()
+        rd = None if reset_draw is None else torch.from_numpy(np.asarray(reset_draw, np.float64)).cuda()
+        self.term.zero_()
+        self.b.step(a, self.obs, self.term, self.rew, self.done, self.trunc, is_last=is_last, reset_draw=rd)
+        return tuple(x.cpu().numpy() for x in (self.obs, self.term, self.rew, self.done, self.trunc))
+
+
+def sync_state(dev: DevBatch, ora: cref.BatchEnv):
+    """Copy the oracle's state into the device batch (identical inputs for a single-step check)."""
+    dev.b.state.copy_(torch.from_numpy(ora.state))
+    dev.b.elapsed.copy_(torch.from_numpy(ora.elapsed))
+    dev.b.ep_ret.copy_(torch.from_numpy(ora.ep_ret))
+    dev.b.ep_len.copy_(torch.from_numpy(ora.ep_len))
+
+
+@pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
+def test_reset_philox_bit_exact(kind):
+    N = 5000
+    dev, ora = DevBatch(kind, N, seed=1234, env_base=10**10), cref.BatchEnv(kind, N, seed=1234, env_base=10**10)
+    for _ in range(3):  # successive resets walk the per-env episode counter
+        o_d, o_c = dev.reset(), ora.reset()
+        assert np.array_equal(dev.b.state.cpu().numpy(), ora.state)          # fp64, bit-exact
+        assert np.allclose(o_d, o_c, rtol=0, atol=6e-8)                      # acrobot: f32 cos/sin of f32 angle
+        assert np.array_equal(dev.b.episode.cpu().numpy().view(np.uint32), ora.episode)
+    lim = 0.05 if kind == "cartpole" else 0.1
+    s = ora.state
+    assert (np.abs(s) <= lim).all() and abs(s.mean()) < lim / 20 and abs(s.std() - 2 * lim / 12**0.5) < lim / 20
+
+
+def test_cartpole_known_answer_first_step():
+    dev = DevBatch("cartpole", 1)
+    dev.reset(np.full((1, 4), 0.5))
+    obs, _, r, d, tr = dev.step([1])
+    st = dev.b.state.cpu().numpy()[0]
+    assert np.allclose(st, [0.0, 0.1951219512195122, 0.0, -0.2926829268292683], rtol=1e-14)
+    assert r[0] == 1.0 and d[0] == 0 and tr[0] == 0 and np.array_equal(obs[0], st.astype(np.float32))
+
+
+@pytest.mark.parametrize("kind,na", [("cartpole", 2), ("acrobot", 3)])
+def test_single_step_from_identical_states(kind, na):
+    """1M independent states covering the whole reachable box, incl. both sides of every threshold."""
+    N = 1 << 20
+    rng = np.random.default_rng(42)
+    dev, ora = DevBatch(kind, N, seed=5), cref.BatchEnv(kind, N, seed=5)
+    dev.reset(); ora.reset()
+    if kind == "cartpole":
+        ora.state[:] = rng.uniform(-1, 1, (N, 4)) * [2.6, 3.0, 0.23, 3.5]
+    else:
+        ora.state[:] = rng.uniform(-1, 1, (N, 4)) * [np.pi, np.pi, 4 * np.pi, 9 * np.pi]
+    ora.elapsed[:] = rng.integers(0, 500, N)
+    ora.elapsed[:1000] = 499
+    sync_state(dev, ora)
+    a = rng.integers(0, na, N)
+    u = rng.random((N, 4))
+    o_d, t_d, r_d, d_d, tr_d = dev.step(a, reset_draw=u)
+    o_c, t_c, r_c, d_c, tr_c = ora.step(a, reset_draw=u)
+    assert np.array_equal(d_d, d_c) and np.array_equal(tr_d, tr_c)           # flags bit-exact
+    assert d_c.sum() > 1000 and tr_c.sum() >= 1000 and ((d_c + tr_c) == 2).sum() > 0
+    assert np.array_equal(r_d, r_c)
+    assert np.array_equal(dev.b.elapsed.cpu().numpy(), ora.elapsed)
+    assert np.array_equal(dev.b.ring_cnt.cpu().numpy(), ora.ring_cnt)
+    assert np.array_equal(dev.b.len_ring.cpu().numpy(), ora.len_ring)
+    st_d = dev.b.state.cpu().numpy()
+    err = np.abs(st_d - ora.state) / np.maximum(np.abs(ora.state), 1e-3)
+    assert err.max() < 1e-12, err.max()                                      # measured: ~1e-15
+    assert np.allclose(o_d, o_c, rtol=RTOL, atol=1e-7) and np.allclose(t_d, t_c, rtol=RTOL, atol=1e-7)
+    frac_bitexact = (st_d == ora.state).mean()
+    print(f"{kind}: fp64 state bit-identical to glibc-libm oracle for {100 * frac_bitexact:.3f}% of values; "
+          f"max rel err {err.max():.2e}")
+
+
+@pytest.mark.parametrize("kind,na,steps", [("cartpole", 2, 1100), ("acrobot", 3, 1100)])
+def test_trajectories_flags_and_episode_lengths_bit_exact(kind, na, steps):
+    """Closed loop over many steps with the same injected actions and reset draws: flags,
+    episode lengths/returns and reset counters must match exactly at every step, states to
+    tolerance; includes TimeLimit truncations (balancing controller on half the CartPoles)."""
+    N = 2048
+    rng = np.random.default_rng(7)
+    dev, ora = DevBatch(kind, N, seed=99), cref.BatchEnv(kind, N, seed=99)
+    u0 = rng.random((N, 4))
+    assert np.allclose(dev.reset(u0), ora.reset(u0), atol=1e-7)
+    n_done = n_trunc = 0
+    for t in range(steps):
+        a = rng.integers(0, na, N)
+        if kind == "cartpole":  # PD controller on the first half so episodes reach 500 steps
+            ctl = (ora.state[:, 2] + 0.5 * ora.state[:, 3] + 0.05 * ora.state[:, 0] + 0.1 * ora.state[:, 1] > 0)
+            a[: N // 2] = ctl[: N // 2]
+        u = rng.random((N, 4))
+        last = (t % 128 == 127)
+        o_d, t_d, r_d, d_d, tr_d = dev.step(a, is_last=last, reset_draw=u)
+        o_c, t_c, r_c, d_c, tr_c = ora.step(a, is_last=last, reset_draw=u)
+        assert np.array_equal(d_d, d_c) and np.array_equal(tr_d, tr_c), f"flags differ at step {t}"
+        assert np.array_equal(r_d, r_c)
+        assert np.allclose(o_d, o_c, rtol=RTOL, atol=1e-6), f"obs differ at step {t}"
+        assert np.allclose(t_d, t_c, rtol=RTOL, atol=1e-6)
+        n_done += int(d_c.sum()); n_trunc += int(((tr_c > 0) & ~last).sum() if not last else 0)
+    assert n_done > 1000
+    if kind == "cartpole":
+        assert n_trunc > 100  # real TimeLimit truncations happened
+    assert np.array_equal(dev.b.elapsed.cpu().numpy(), ora.elapsed)
+    assert np.array_equal(dev.b.ep_len.cpu().numpy(), ora.ep_len)
+    assert np.array_equal(dev.b.ep_ret.cpu().numpy(), ora.ep_ret)
+    assert np.array_equal(dev.b.ring_cnt.cpu().numpy(), ora.ring_cnt)
+    assert np.array_equal(dev.b.len_ring.cpu().numpy(), ora.len_ring)        # episode lengths bit-exact
+    assert np.array_equal(dev.b.ret_ring.cpu().numpy(), ora.ret_ring)
+    assert np.array_equal(dev.b.episode.cpu().numpy().view(np.uint32), ora.episode)
+    assert np.allclose(dev.b.state.cpu().numpy(), ora.state, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
+def test_native_philox_resets_match_oracle_stream(kind):
+    """No injected draws: device and oracle consume the same Philox stream keyed by global env id."""
+    N, base = 777, 123456789012
+    rng = np.random.default_rng(1)
+    dev, ora = DevBatch(kind, N, seed=31337, env_base=base), cref.BatchEnv(kind, N, seed=31337, env_base=base)
+    dev.reset(); ora.reset()
+    na = 2 if kind == "cartpole" else 3
+    for t in range(300):
+        a = rng.integers(0, na, N)
+        o_d, _, _, d_d, tr_d = dev.step(a)
+        o_c, _, _, d_c, tr_c = ora.step(a)
+        assert np.array_equal(d_d, d_c) and np.array_equal(tr_d, tr_c)
+        assert np.allclose(o_d, o_c, rtol=RTOL, atol=1e-6)
+    assert ora.episode.max() > 3
+    # sharding invariance: the second half as its own batch with env_base shifted gives the same resets
+    half = DevBatch(kind, N - 400, seed=31337, env_base=base + 400)
+    full = DevBatch(kind, N, seed=31337, env_base=base)
+    assert np.array_equal(half.reset(), full.reset()[400:])
+
+
+def test_forced_truncation_and_empty_batch():
+    dev = DevBatch("cartpole", 3)
+    dev.reset(np.full((3, 4), 0.5))
+    obs, term, _, d, tr = dev.step([1, 0, 1], is_last=True)
+    assert d.tolist() == [0, 0, 0] and tr.tolist() == [1, 1, 1]
+    assert np.array_equal(obs, term) and dev.b.elapsed.tolist() == [1, 1, 1] and dev.b.ring_cnt.sum().item() == 0
+    from ppo_amd import _lib
+    assert _lib.load().ppo_env_step(0, None, None, None, None, None, None, None, 0, 0, None, None, None, None,
+                                    None, None, None, None, 0, 0, 0, None) == 0  # N = 0 is a no-op
+
+
+def test_categorical_sample_distribution_and_logp():
+    from ppo_amd import ops
+    N, A = 1 << 18, 3
+    logits = torch.tensor([[0.3, -1.2, 0.9]]).repeat(N, 1).cuda()
+    a, lp = ops.categorical_sample(logits, seed=11, env_base=0, step=5)
+    assert a.dtype == torch.int32 and lp.dtype == torch.float32 and int(a.min()) >= 0 and int(a.max()) < A
+    want_lp = torch.log_softmax(logits, dim=1)
+    assert torch.allclose(lp, want_lp.gather(1, a.long()[:, None])[:, 0], rtol=1e-5, atol=1e-6)
+    freq = torch.bincount(a.long(), minlength=A).double() / N
+    p = torch.softmax(logits[0].double(), 0)
+    assert (freq - p).abs().max() < 5 * (0.25 / N) ** 0.5                     # 5 sigma
+    a2, _ = ops.categorical_sample(logits, seed=11, env_base=0, step=5)
+    a3, _ = ops.categorical_sample(logits, seed=11, env_base=0, step=6)
+    assert torch.equal(a, a2) and not torch.equal(a, a3)

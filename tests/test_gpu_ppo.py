@@ -1,0 +1,159 @@
+"""GPU: the Python surface (PPO / SyncVecEnv / Agent) on the kernels -- the reference's
+tests/test_vec_env.py and tests/test_ppo.py::test_cartpole contracts, plus rollout parity of
+the device path against the oracle's serial restatement of the reference loop."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref, pyref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vec_env_states():
+    """reference tests/test_vec_env.py:11-24 (CartPole part; ALE is not installed)"""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.env_cartpole import train_fn as env_fn
+    test_env = env_fn()
+    agent = Agent(test_env.observation_space, test_env.action_space, conv_net=0, joint_net=1, device="cpu")
+    vec_env = SyncVecEnv(env_fn, num_envs=6, steps_per_env=125, render_every=0, render_fps=0.0, agent=agent)
+    states = vec_env.vec_reset()
+    assert states.size() == torch.Size([6, 4])
+    assert states.dtype == torch.float32
+
+
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+def test_vec_env_rollout(device):
+    """reference tests/test_vec_env.py:39-62"""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.env_cartpole import train_fn as env_fn
+
+    def matching_shape_dtype(x, shape, dtype):
+        assert x.size() == torch.Size(shape)
+        assert x.dtype == dtype
+
+    test_env = env_fn()
+    agent = Agent(test_env.observation_space, test_env.action_space, conv_net=0, joint_net=1, device=device)
+    vec_env = SyncVecEnv(env_fn, num_envs=2, steps_per_env=125, render_every=0, render_fps=0.0, agent=agent)
+    vec_env.rollout()
+    assert vec_env.states.requires_grad
+    matching_shape_dtype(vec_env.states, (125, 2, 4), torch.float32)
+    matching_shape_dtype(vec_env.actions, (125, 2), torch.int32)
+    matching_shape_dtype(vec_env.rewards, (125, 2), torch.float32)
+    matching_shape_dtype(vec_env.done_flags, (125, 2), torch.int32)
+    matching_shape_dtype(vec_env.trunc_flags, (125, 2), torch.int32)
+    matching_shape_dtype(vec_env.values, (125, 2), torch.float32)
+    matching_shape_dtype(vec_env.log_probs, (125, 2), torch.float32)
+    # rollout invariants of reference src/ppo.py:352-356, :377-379, :401-402
+    ended = (vec_env.done_flags + vec_env.trunc_flags) > 0
+    assert bool(ended[-1].all())
+    assert vec_env.end_states.shape == (int(ended.sum()), 4)
+    assert vec_env.global_steps == 250 and vec_env.total_return == np.float32(250.0)
+
+
+@pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
+def test_device_rollout_matches_serial_reference_loop(kind):
+    """Same policy, same sampled actions (replayed), same reset draws (Philox): the fused device
+    rollout and the oracle's restatement of the reference's serial loop (src/ppo.py:320-402) give
+    the same buffers -- flags exact, the rest to f32 tolerance -- over two consecutive rollouts."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    torch.manual_seed(0)
+    N, T, seed = 64, 96, 2024
+    probe = DeviceEnv(kind)
+    agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
+    ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=seed), N, T, 0, 0.0, agent, seed=seed)
+
+    ora = cref.BatchEnv(kind, N, seed=seed)
+    t_states = torch.from_numpy(ora.reset())
+    assert np.allclose(ve.t_states.cpu().numpy(), t_states.numpy(), atol=1e-7)
+
+    class OracleEnv:  # gym.Env protocol view of one oracle env, resets drawn from the same Philox stream
+        def __init__(self, i):
+            self.i = i
+            self.b = cref.BatchEnv(kind, 1, seed=seed, env_base=i)
+            self.b.reset()
+
+        def reset(self):
+            return self.b.reset()[0], {}
+
+        def step(self, a):
+            # step WITHOUT the fused bookkeeping: plain env.step semantics
+            st, el = self.b.state.copy(), self.b.elapsed.copy()
+            import ctypes as C
+            obs = np.empty(self.b.od, np.float32); r = C.c_float()
+            fn = cref.lib().oracle_cartpole_step if kind == "cartpole" else cref.lib().oracle_acrobot_step
+            f = fn(self.b.state.ctypes.data_as(C.POINTER(C.c_double)), self.b.elapsed.ctypes.data_as(C.POINTER(C.c_int)),
+                   C.c_int(int(a)), obs.ctypes.data_as(C.POINTER(C.c_float)), C.byref(r))
+            return obs, r.value, bool(f & 1), bool(f & 2), {}
+
+    envs = [OracleEnv(i) for i in range(N)]
+    for k in range(2):
+        ve.rollout()
+        acts = ve.actions.cpu()
+        step = {"t": 0}
+
+        def policy(states):
+            t = step["t"]; step["t"] += 1
+            a = acts[t]
+            lp, v = ve.log_probs[t].cpu(), ve.values[t].cpu()
+            return a, lp, v
+
+        ref = pyref.serial_rollout(envs, t_states, policy, T)
+        t_states = ref["t_states"]
+        assert torch.equal(ve.done_flags.cpu(), ref["done"]) and torch.equal(ve.trunc_flags.cpu(), ref["trunc"])
+        assert torch.equal(ve.rewards.cpu(), ref["rewards"])
+        assert torch.allclose(ve.states.detach().cpu(), ref["states"], rtol=1e-5, atol=1e-6)
+        assert ve.end_states.shape == ref["end_states"].shape
+        assert torch.allclose(ve.end_states.cpu(), ref["end_states"], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(ve.t_states.cpu(), t_states, rtol=1e-5, atol=1e-6)
+        # the policy outputs recorded by the fused sampler are consistent with the agent
+        with torch.no_grad():
+            logits, vals = agent.policy_and_values(ve.states.detach()[5])
+        lp = torch.log_softmax(logits, 1).gather(1, ve.actions[5].long()[:, None])[:, 0]
+        assert torch.allclose(lp, ve.log_probs[5], rtol=1e-5, atol=1e-6) and torch.allclose(vals, ve.values[5])
+        assert int(ref["done"].sum()) > 0 or kind == "acrobot"
+
+
+def test_train_step_advantages_dense_equals_reference_form():
+    """PPO.train_step's dense-bootstrap GAE equals the drop-in ragged compute_advantages."""
+    from ppo_amd import PPO
+    from ppo_amd.env_cartpole import train_fn
+    ppo = PPO(0.99, 0.95, 1, 1, 0, 0, True, seed=3)
+    ppo.train(train_fn, num_updates=1, num_envs=256, steps_per_env=64, num_epochs=1, batch_size=4096,
+              critic_coef=0.5, entropy_coef=0.01, clip_ratio=0.2, max_grad_norm=0.5, learning_rate=3e-4)
+    ve = ppo.vec_env
+    with torch.no_grad():
+        ev = ppo.agent.get_values(ve.end_states)
+        dense = ppo._advantages(ve, ev)
+        ragged = ppo.compute_advantages(ve.rewards, ve.values, ev, ve.done_flags, ve.trunc_flags)
+    assert torch.equal(dense, ragged)
+    m = ppo.last_metrics
+    assert set(m) >= {"utils/env_steps_per_sec", "losses/policy_loss", "metrics/kl_div", "metrics/ep_return_max"}
+    assert np.isfinite(m["losses/policy_loss"]) and m["utils/env_steps_per_sec"] > 0
+
+
+def test_cartpole():
+    """reference tests/test_ppo.py:124-159: same hyper-parameters, same thresholds."""
+    from ppo_amd import PPO
+    from ppo_amd.env_cartpole import train_fn as env_fn
+    ppo = PPO(discount_factor=0.99, gae_factor=0.95, norm_adv=1, clip_va_loss=1, conv_net=0, joint_network=0,
+              use_gpu=True)
+    time_start = time.time()
+    ppo.train(env_fn=env_fn, num_updates=200, num_envs=4, steps_per_env=125, num_epochs=4, batch_size=128,
+              critic_coef=0.5, entropy_coef=0.01, clip_ratio=0.2, max_grad_norm=0.5, learning_rate=3e-4,
+              target_div=0.01)
+    train_time_limit = 60
+    ep_return_threshold = 250
+    assert time.time() - time_start < train_time_limit
+    assert ppo.vec_env.max_ep_return > ep_return_threshold
+
+
+def test_cli_plumbing_config1():
+    """BASELINE config 1: CartPole, 8 envs x 128 steps through the CLI's positional arguments."""
+    from ppo_amd import ppo_cli
+    argv = "plumb env_cartpole 2 8 128 4 128 0.5 0.01 0.2 0.5 3e-4 0.99 0.95 1 1 0 0 --use_gpu 1".split()
+    agent = ppo_cli.main(argv)
+    assert agent.updates == 2 and agent.vec_env.num_envs == 8 and agent.last_metrics["utils/env_steps_per_sec"] > 0
