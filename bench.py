@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--num-envs", type=int, default=65536, help="envs PER GPU")
     p.add_argument("--rollout-len", type=int, default=128)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-envs", type=int, default=1024)
+    p.add_argument("--cpu-sample-envs", type=int, default=4096)
     p.add_argument("--seed", type=int, default=0)
     return p.parse_args()
 

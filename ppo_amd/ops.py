@@ -132,35 +132,41 @@ def loss_fwd_bwd(x, old_lp, new_v, old_v, adv, clip, norm_adv, clip_va, ratio_in
     return out4, g_x, g_v
 
 
-class _PPOLossFn(torch.autograd.Function):
-    """Autograd node around ppo_loss_fwd_bwd.  The kernel produces both losses and both
-    per-sample gradients in one pass; backward only scales them by the upstream scalars."""
+class _AttachGrad(torch.autograd.Function):
+    """value(inp) with d value / d inp = grad, both precomputed by ppo_loss_fwd_bwd.
+
+    Policy loss and value loss get one node EACH (fed by the same kernel launch): with split
+    networks the reference back-propagates the two losses separately and steps the policy
+    optimiser in between (reference src/ppo.py:614-625), so the value loss must not be connected
+    to the policy branch of the graph."""
 
     @staticmethod
-    def forward(ctx, x, new_v, old_lp, old_v, adv, clip, norm_adv, clip_va, ratio_input, stats3):
-        out4, g_x, g_v = loss_fwd_bwd(x, old_lp, new_v, old_v, adv, clip, norm_adv, clip_va, ratio_input,
-                                      stats3=stats3, want_grads=True)
-        ctx.save_for_backward(g_x, g_v)
-        ctx.x_meta = (x.shape, x.device)
-        ctx.v_meta = (new_v.shape, new_v.device)
-        o = out4.to(x.device)
-        pl, vl, cf, kl = o[0], o[1], o[2], o[3]
-        ctx.mark_non_differentiable(cf, kl)
-        return pl, vl, cf, kl
+    def forward(ctx, inp, value, grad):
+        ctx.save_for_backward(grad)
+        ctx.meta = (inp.shape, inp.device)
+        return value.clone()
 
     @staticmethod
-    def backward(ctx, g_pl, g_vl, _g_cf, _g_kl):
-        g_x, g_v = ctx.saved_tensors
-        (xs, xd), (vs, vd) = ctx.x_meta, ctx.v_meta
-        gx = (g_x * g_pl.to(g_x.device)).to(xd).reshape(xs) if ctx.needs_input_grad[0] else None
-        gv = (g_v * g_vl.to(g_v.device)).to(vd).reshape(vs) if ctx.needs_input_grad[1] else None
-        return gx, gv, None, None, None, None, None, None, None, None
+    def backward(ctx, g_out):
+        (grad,) = ctx.saved_tensors
+        shape, dev = ctx.meta
+        return (grad * g_out.to(grad.device)).to(dev).reshape(shape), None, None
 
 
 def ppo_losses(x, new_v, old_lp, old_v, adv, clip, norm_adv, clip_va, ratio_input, stats3=None):
-    """Differentiable (policy_loss, value_loss, clip_frac, kl_div), each 0-d f32."""
-    return _PPOLossFn.apply(x, new_v, old_lp, old_v, adv, float(clip), bool(norm_adv), bool(clip_va),
-                            bool(ratio_input), stats3)
+    """(policy_loss, value_loss, clip_frac, kl_div), each 0-d f32 on x.device; the first two are
+    differentiable w.r.t. x (ratios or new log-probs) and new_v respectively."""
+    need = torch.is_grad_enabled() and (x.requires_grad or new_v.requires_grad)
+    with torch.no_grad():
+        out4, g_x, g_v = loss_fwd_bwd(x, old_lp, new_v, old_v, adv, float(clip), bool(norm_adv), bool(clip_va),
+                                      bool(ratio_input), stats3=stats3, want_grads=need)
+        o = out4.to(x.device)
+    pl, vl, cf, kl = o[0], o[1], o[2], o[3]
+    if need and x.requires_grad:
+        pl = _AttachGrad.apply(x, pl, g_x)
+    if need and new_v.requires_grad:
+        vl = _AttachGrad.apply(new_v, vl, g_v)
+    return pl, vl, cf, kl
 
 
 # --------------------------------------------------------------------------- sampling

@@ -1,0 +1,53 @@
+"""Time every (VEC, U) instantiation of the GAE kernel at a given shape (tuning aid).
+Buffers are rotated over `--sets` independent copies so that repeated launches are not served
+from the 256 MiB Infinity Cache (one C2 working set is 201 MB)."""
+import argparse
+import json
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ppo_amd import ops
+
+p = argparse.ArgumentParser()
+p.add_argument("--T", type=int, default=128)
+p.add_argument("--N", type=int, default=65536)
+p.add_argument("--sets", type=int, default=4)
+p.add_argument("--iters", type=int, default=40)
+p.add_argument("--variants", default="0,1,2,3,4,5,6,7")
+a = p.parse_args()
+T, N = a.T, a.N
+g = torch.Generator(device="cuda").manual_seed(1234)
+sets = []
+for _ in range(a.sets):
+    r = torch.randn((T, N), device="cuda", generator=g)
+    v = torch.randn((T, N), device="cuda", generator=g)
+    ev = torch.randn((T, N), device="cuda", generator=g)
+    d = (torch.rand((T, N), device="cuda", generator=g) < 1 / 50).int()
+    tr = ((torch.rand((T, N), device="cuda", generator=g) < 1 / 500) & (d == 0)).int()
+    tr[T - 1] = 1 - d[T - 1]
+    sets.append((r, v, ev, d, tr, torch.empty_like(r)))
+bytes_ = 24 * T * N
+res = {}
+for variant in [int(x) for x in a.variants.split(",")]:
+    vec = {3: 2, 4: 2, 5: 4, 6: 4}.get(variant, 1)
+    if N % vec:
+        continue
+    for i in range(3):
+        s = sets[i % len(sets)]
+        ops.gae_dense(*s[:5], 0.99, 0.95, out=s[5], variant=variant)
+    torch.cuda.synchronize()
+    times = []
+    for i in range(a.iters):
+        s = sets[i % len(sets)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.gae_dense(*s[:5], 0.99, 0.95, out=s[5], variant=variant)
+        e1.record()
+        times.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = sorted(x.elapsed_time(y) * 1e3 for x, y in times)
+    med = ts[len(ts) // 2]
+    res[variant] = {"median_us": med, "min_us": ts[0], "GBps_median": bytes_ / med / 1e3}
+    print(f"variant {variant}: median {med:8.1f} us  min {ts[0]:8.1f} us  -> {bytes_ / med / 1e3:7.0f} GB/s "
+          f"({100 * bytes_ / med / 1e3 / 8000:.1f}% of 8 TB/s)", flush=True)
+print(json.dumps({"T": T, "N": N, "sets": a.sets, "results": res}))
