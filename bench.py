@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-GAE_BYTES_PER_ELEM = 24        # r, v, done, trunc, end_value read + adv written
+GAE_BYTES_PER_ELEM = 20        # r, v, done, trunc read + adv written; the end value is read only where
+                               # trunc != 0 (4 B more for those cells).  SURVEY.md 8d's dense count is 24.
 
 
 def parse():
@@ -112,12 +113,17 @@ def main():
             end_values = agent.get_values(ve.end_states)
             ev_dense = ppo._scatter_end_values(ve, end_values)
             if record:
+                # The host has just synchronised (end_states size), so the GPU is idle and an event
+                # pair would also time the host's launch latency.  A ~40 us on-GPU spin queued FIRST
+                # lets the host run ahead; e0 then fires when the spin ends and the GAE kernel is
+                # already in the queue, so e1 - e0 is the kernel's duration (agrees with rocprofv3).
+                torch.cuda._sleep(100_000)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95)
             if record:
                 e1.record()
-                gae_events.append((e0, e1))
+                gae_events.append((e0, e1, int((ve.trunc_flags != 0).sum())))
         return adv
 
     def barrier():
@@ -138,8 +144,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    gae_ms = float(np.mean([a.elapsed_time(b) for a, b in gae_events]))
-    gae_bytes = GAE_BYTES_PER_ELEM * T * N
+    gae_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in gae_events]))
+    n_trunc = float(np.mean([n for _, _, n in gae_events]))
+    gae_bytes = int(GAE_BYTES_PER_ELEM * T * N + 4 * n_trunc)
     achieved = gae_bytes / (gae_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "gae_pmc_traffic.json")
@@ -160,7 +167,10 @@ def main():
                        "num_envs_per_gpu": N, "rollout_len": T, "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "k_gae (ppo_gae_dense)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes},
+                         "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes,
+                         "achieved_if_dense_24B_per_elem": 24 * T * N / (gae_ms * 1e-3) / 1e9,
+                         "note": "algorithmic bytes = 20 B/element (r, v, done, trunc in; adv out) + 4 B per "
+                                 "truncated cell; SURVEY.md 8d's dense convention (24 B/element) is given beside it"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, args.cpu_sample_envs, T, args.seed)

@@ -29,6 +29,7 @@ SIGNATURES = {
 # tuning hook, deliberately not in the public header
 _PRIVATE = {
     "ppo_gae_dense_variant": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
+    "ppo_stream_ceiling": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
 }
 
 _lib = None

@@ -1,7 +1,8 @@
 // GAE(lambda) reverse-time scan over the [T, N] rollout buffer -- gfx950.
 //
-// Replaces PPO.compute_advantages (reference src/ppo.py:452-488).  HBM-bound: 24 B per
-// (t, n) element (r, v, done, trunc, end_value read; adv written), ~6 flops.  No MFMA.
+// Replaces PPO.compute_advantages (reference src/ppo.py:452-488).  HBM-bound: 20 B per
+// (t, n) element (r, v, done, trunc read; adv written) + the end value where trunc != 0
+// (24 B if the dense end-value buffer is streamed), ~6 flops.  No MFMA.
 //
 // Mapping: one lane owns VEC adjacent env columns and walks time backwards; consecutive
 // lanes own consecutive columns, so every wave-level load/store is one contiguous
@@ -147,6 +148,136 @@ __global__ void __launch_bounds__(256) k_gae(GaeArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Sparse-bootstrap form of the column-per-lane kernel.  end_value_dense is only ever used
+// where trunc != 0 (one forced row per rollout plus the rare TimeLimit hits), so streaming
+// it costs 4 of the 24 bytes per element for nothing.  Here the r/v/done/trunc loads run two
+// blocks ahead, the flags of the NEXT block (already landed) decide -- per lane -- whether
+// its end-value rows are fetched at all, and those few loads are in flight while the
+// CURRENT block is consumed.  HBM traffic drops to 20 B per element plus ~one 64-byte
+// sector per truncation.
+template <int VEC, int U> struct FlagBlock {
+    typename VecT<VEC>::F r[U], v[U];
+    typename VecT<VEC>::I d[U], tr[U];
+};
+template <int VEC, int U> struct EvBlock {
+    typename VecT<VEC>::F ev[U];
+};
+
+template <int VEC, int U>
+__device__ __forceinline__ void load_flags(FlagBlock<VEC, U> &b, const GaeArgs &a, size_t col, int t_top)
+{
+    using F = typename VecT<VEC>::F;
+    using I = typename VecT<VEC>::I;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t o = (size_t)(t_top - u) * (size_t)a.N + col;
+        b.r[u] = *reinterpret_cast<const F *>(a.r + o);
+        b.v[u] = *reinterpret_cast<const F *>(a.v + o);
+        b.d[u] = *reinterpret_cast<const I *>(a.done + o);
+        b.tr[u] = *reinterpret_cast<const I *>(a.trunc + o);
+    }
+}
+
+template <int VEC, int U>
+__device__ __forceinline__ void load_ev_sparse(EvBlock<VEC, U> &e, const FlagBlock<VEC, U> &b, const GaeArgs &a,
+                                               size_t col, int t_top)
+{
+    using F = typename VecT<VEC>::F;
+    int any = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) any |= iget<VEC>(b.tr[u], k);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) fset<VEC>(e.ev[u], k, 0.0f);
+    if (any) {  // one branch per block; only lanes that saw a truncation issue loads
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            e.ev[u] = *reinterpret_cast<const F *>(a.ev + (size_t)(t_top - u) * (size_t)a.N + col);
+    }
+}
+
+template <int VEC, int U>
+__device__ __forceinline__ void consume_sparse(const FlagBlock<VEC, U> &b, const EvBlock<VEC, U> &e, const GaeArgs &a,
+                                               size_t col, int t_top, float (&nv)[VEC], float (&na)[VEC])
+{
+    using F = typename VecT<VEC>::F;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        F out, rout;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int d = iget<VEC>(b.d[u], k), tr = iget<VEC>(b.tr[u], k);
+            const float ev = tr ? fget<VEC>(e.ev[u], k) : 0.0f;
+            const float v = fget<VEC>(b.v[u], k);
+            const float adv = gae_step(fget<VEC>(b.r[u], k), v, d, tr, ev, a.g, a.gl, nv[k], na[k]);
+            fset<VEC>(out, k, adv);
+            fset<VEC>(rout, k, adv + v);
+        }
+        const size_t o = (size_t)(t_top - u) * (size_t)a.N + col;
+        *reinterpret_cast<F *>(a.adv + o) = out;
+        if (a.ret) *reinterpret_cast<F *>(a.ret + o) = rout;
+    }
+}
+
+template <int VEC, int U>
+__global__ void __launch_bounds__(256) k_gae_sparse(GaeArgs a)
+{
+    const size_t col = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (col >= (size_t)a.N) return;
+    float nv[VEC], na[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { nv[k] = 0.0f; na[k] = 0.0f; }
+
+    const int nblk = a.T / U;
+    int t = a.T - 1;
+    FlagBlock<VEC, U> f0, f1, f2;   // blocks b, b+1, b+2
+    EvBlock<VEC, U> e0, e1;         // end values of blocks b, b+1
+    if (nblk > 0) load_flags<VEC, U>(f0, a, col, t);
+    if (nblk > 1) load_flags<VEC, U>(f1, a, col, t - U);
+    if (nblk > 0) load_ev_sparse<VEC, U>(e0, f0, a, col, t);
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 2 < nblk) load_flags<VEC, U>(f2, a, col, t - 2 * U);
+        if (b + 1 < nblk) load_ev_sparse<VEC, U>(e1, f1, a, col, t - U);
+        consume_sparse<VEC, U>(f0, e0, a, col, t, nv, na);
+        f0 = f1; f1 = f2; e0 = e1;
+        t -= U;
+    }
+    for (; t >= 0; --t) {
+        FlagBlock<VEC, 1> f;
+        EvBlock<VEC, 1> e;
+        load_flags<VEC, 1>(f, a, col, t);
+        load_ev_sparse<VEC, 1>(e, f, a, col, t);
+        consume_sparse<VEC, 1>(f, e, a, col, t, nv, na);
+    }
+}
+
+template <int VEC, int U> int launch_gae_sparse(const GaeArgs &a, hipStream_t s)
+{
+    const long threads = a.N / VEC;
+    const long waves = (threads + 63) / 64;
+    const int block = waves <= 2048 ? 64 : 256;
+    const long grid = (threads + block - 1) / block;
+    hipLaunchKernelGGL((k_gae_sparse<VEC, U>), dim3((unsigned)grid), dim3(block), 0, s, a);
+    return ppo_launch_status();
+}
+
+// A pure streaming kernel with the GAE traffic mix (5 x 4 B read, 4 B written per element,
+// 16 B per lane, full occupancy): the measured ceiling the scan kernels are compared to.
+__global__ void __launch_bounds__(256) k_stream_ceiling(const float4 *r, const float4 *v, const float4 *ev,
+                                                        const int4 *d, const int4 *tr, float4 *out, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = r[i], b = v[i], c = ev[i];
+        const int4 e = d[i], f = tr[i];
+        out[i] = make_float4(a.x + b.x + c.x + (float)(e.x + f.x), a.y + b.y + c.y + (float)(e.y + f.y),
+                             a.z + b.z + c.z + (float)(e.z + f.z), a.w + b.w + c.w + (float)(e.w + f.w));
+    }
+}
+
 // --- ragged pre-pass: ep_counts (src/ppo.py:468) and cumsum - 1 (:469) ------------
 __global__ void __launch_bounds__(256) k_ep_counts(const int *done, const int *trunc, long *counts, int T, int N)
 {
@@ -218,22 +349,22 @@ template <int VEC, int U, bool DENSE_EV> int launch_gae(const GaeArgs &a, hipStr
     return ppo_launch_status();
 }
 
+// Variant table (tools/tune_gae.py; numbers in DESIGN.md).  0-1 stream the dense end-value
+// buffer, 2-5 fetch it only where a truncation is flagged.
 int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s)
 {
     switch (variant) {
     case 0: return launch_gae<1, 8, true>(a, s);
-    case 1: return launch_gae<1, 4, true>(a, s);
-    case 2: return launch_gae<1, 16, true>(a, s);
-    case 3: return launch_gae<2, 4, true>(a, s);
-    case 4: return launch_gae<2, 8, true>(a, s);
-    case 5: return launch_gae<4, 2, true>(a, s);
-    case 6: return launch_gae<4, 4, true>(a, s);
-    case 7: return launch_gae<1, 2, true>(a, s);
+    case 1: return launch_gae<2, 4, true>(a, s);
+    case 2: return launch_gae_sparse<1, 4>(a, s);
+    case 3: return launch_gae_sparse<1, 8>(a, s);
+    case 4: return launch_gae_sparse<2, 4>(a, s);
+    case 5: return launch_gae_sparse<2, 8>(a, s);
     default: return (int)hipErrorInvalidValue;
     }
 }
 
-int variant_vec(int variant) { return variant == 3 || variant == 4 ? 2 : (variant == 5 || variant == 6 ? 4 : 1); }
+int variant_vec(int variant) { return (variant == 1 || variant == 4 || variant == 5) ? 2 : 1; }
 
 }  // namespace
 
@@ -263,10 +394,25 @@ int ppo_gae_dense(const float *rewards, const float *values, const float *end_va
                   float *ret, int T, int N, void *stream)
 {
     PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
-    // Variant choice (measured on MI355X): VEC=1/U=8 unless the caller's
-    // shape allows nothing else; wider VEC needs N % VEC == 0 and aligned bases.
+    // Measured on MI355X at T=128, N=65536: sparse end values, two columns per lane,
+    // 8-row blocks is the fastest form; it needs an even N and 8-byte aligned bases.
+    const bool vec2 = (N % 2 == 0) && ppo_aligned(rewards, 8) && ppo_aligned(values, 8) &&
+                      ppo_aligned(end_value_dense, 8) && ppo_aligned(done, 8) && ppo_aligned(trunc, 8) &&
+                      ppo_aligned(adv, 8) && (!ret || ppo_aligned(ret, 8));
     return ppo_gae_dense_variant(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
-                                 0, stream);
+                                 vec2 ? 5 : 3, stream);
+}
+
+// Tuning hook: streaming ceiling with the GAE traffic mix (n elements, 16-byte aligned, n % 4 == 0).
+int ppo_stream_ceiling(const float *r, const float *v, const float *ev, const int *d, const int *tr, float *out,
+                       long n, void *stream)
+{
+    PPO_REQUIRE(r && v && ev && d && tr && out && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(k_stream_ceiling, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(r), reinterpret_cast<const float4 *>(v),
+                       reinterpret_cast<const float4 *>(ev), reinterpret_cast<const int4 *>(d),
+                       reinterpret_cast<const int4 *>(tr), reinterpret_cast<float4 *>(out), (size_t)n / 4);
+    return ppo_launch_status();
 }
 
 size_t ppo_gae_ragged_workspace_bytes(int N) { return N > 0 ? (size_t)N * sizeof(long) : 0; }
