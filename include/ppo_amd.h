@@ -155,6 +155,32 @@ int ppo_loss_fwd_bwd(const float *x, const float *old_lp, const float *new_v,
 int ppo_categorical_sample(const float *logits, int A, uint64_t seed, uint64_t env_base,
                            uint64_t step, int *action, float *logp, int N, void *stream);
 
+/* Number of floats in the packed dense-network parameter buffer ppo_rollout_fused reads
+ * (layout in ppo_amd/csrc/rollout.hip; built by ppo_amd.ops.pack_dense_agent). */
+size_t ppo_rollout_param_floats(int kind, int joint);
+
+/*
+ * A whole T-step rollout of N envs in ONE launch: per time step the dense 64-64 tanh policy /
+ * value network forward, Categorical sampling + log-prob, and the fused env transition of
+ * ppo_env_step, with every [T,N] rollout buffer written in place.  Replaces the loop body of
+ * SyncVecEnv.rollout (src/ppo.py:320-398) together with Agent.get_actions_and_values for the
+ * dense network with a Discrete head (src/ppo.py:124-145,166-216) on CartPole / Acrobot.
+ *   params      packed f32 network (ppo_rollout_param_floats), joint != 0: shared backbone
+ *   sample_step0  Philox position of time step 0 (same stream as ppo_categorical_sample)
+ *   obs_io      [N,obs_dim] f32: current observations in, carried observations out (:398)
+ *   states [T,N,obs_dim] f32, actions [T,N] i32, log_probs/values/rewards [T,N] f32,
+ *   done/trunc [T,N] i32, term_obs [T,N,obs_dim] f32 (written where done+trunc > 0)
+ * Env state arguments and rings as in ppo_env_step; row T-1 gets the forced truncation.
+ * Network arithmetic is f32 FMA; values / log-probs agree with the PyTorch forward of the same
+ * parameters to ~1e-6 (different summation order than hipBLASLt), not bit for bit.
+ */
+int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len,
+                      uint32_t *episode, const double *reset_draw, uint64_t seed,
+                      uint64_t env_base, const float *params, int joint, uint64_t sample_step0,
+                      float *obs_io, float *states, int *actions, float *log_probs, float *values,
+                      float *rewards, int *done, int *trunc, float *term_obs, float *ret_ring,
+                      int *len_ring, int *ring_cnt, int ring, int N, int T, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,278 @@
+// Shared device code of the env kernels: CartPole-v1 / Acrobot-v1 physics, reset draws and the
+// fused per-env transition (step + TimeLimit + episode statistics + forced last-step truncation +
+// terminal-observation capture + auto-reset).  Included by env.hip (one launch per time step) and
+// rollout.hip (whole rollout in one launch).
+#pragma once
+#include "common.h"
+
+namespace ppo_env {
+
+
+constexpr int MAX_EPISODE_STEPS = 500;  // TimeLimit of CartPole-v1 and Acrobot-v1
+constexpr double PI = 3.14159265358979323846;
+
+struct EnvArgs {
+    double *state;
+    int *elapsed;
+    float *ep_ret;
+    int *ep_len;
+    uint32_t *episode;
+    const int *action;
+    const double *reset_draw;
+    uint64_t seed, env_base;
+    float *obs_out, *term_obs, *reward;
+    int *done, *trunc;
+    float *ret_ring;
+    int *len_ring, *ring_cnt;
+    int ring, N, is_last;
+};
+
+// ---- CartPole-v1 ---------------------------------------------------------------------
+struct CartPole {
+    static constexpr int OBS = 4;
+
+    __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[k] = -0.05 + (0.05 - -0.05) * u[k];
+            obs[k] = (float)s[k];
+        }
+    }
+
+    // returns terminated; reward is always 1.0
+    __device__ static bool step(double (&s)[4], int action, float (&obs)[6], float &reward)
+    {
+        const double gravity = 9.8, masscart = 1.0, masspole = 0.1;
+        const double total_mass = masspole + masscart;
+        const double length = 0.5;
+        const double polemass_length = masspole * length;
+        const double force_mag = 10.0, tau = 0.02;
+        const double theta_thr = 12 * 2 * PI / 360;
+        const double x_thr = 2.4;
+
+        double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+        const double force = (action == 1) ? force_mag : -force_mag;
+        const double costheta = cos(theta);
+        const double sintheta = sin(theta);
+        const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+        const double thetaacc = (gravity * sintheta - costheta * temp) /
+                                (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+        const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+        x = x + tau * x_dot;
+        x_dot = x_dot + tau * xacc;
+        theta = theta + tau * theta_dot;
+        theta_dot = theta_dot + tau * thetaacc;
+        s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
+        reward = 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) obs[k] = (float)s[k];
+        return (x < -x_thr) || (x > x_thr) || (theta < -theta_thr) || (theta > theta_thr);
+    }
+};
+
+// ---- Acrobot-v1 ("book" dynamics, RK4 over [0, 0.2] in registers) -----------------------
+struct Acrobot {
+    static constexpr int OBS = 6;
+
+    __device__ static void write_obs(const double (&s)[4], float (&obs)[6])
+    {
+        obs[0] = (float)cos(s[0]); obs[1] = (float)sin(s[0]);
+        obs[2] = (float)cos(s[1]); obs[3] = (float)sin(s[1]);
+        obs[4] = (float)s[2]; obs[5] = (float)s[3];
+    }
+
+    __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = (double)(float)(-0.1 + (0.1 - -0.1) * u[k]);  // .astype(float32)
+        write_obs(s, obs);
+    }
+
+    __device__ static void dsdt(const double (&y)[4], double a, double (&out)[4])
+    {
+        const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
+        const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
+        const double c2 = cos(theta2), s2 = sin(theta2);
+        const double d1 = m1 * (lc1 * lc1) + m2 * ((l1 * l1) + (lc2 * lc2) + 2 * l1 * lc2 * c2) + I1 + I2;
+        const double d2 = m2 * ((lc2 * lc2) + l1 * lc2 * c2) + I2;
+        const double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - PI / 2.0);
+        const double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2
+                            - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2
+                            + (m1 * lc1 + m2 * l1) * g * cos(theta1 - PI / 2)
+                            + phi2;
+        const double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                                (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+        const double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+        out[0] = dtheta1; out[1] = dtheta2; out[2] = ddtheta1; out[3] = ddtheta2;
+    }
+
+    __device__ static double wrap(double x, double m, double M)
+    {
+        const double diff = M - m;
+        while (x > M) x = x - diff;
+        while (x < m) x = x + diff;
+        return x;
+    }
+
+    __device__ static bool step(double (&s)[4], int action, float (&obs)[6], float &reward)
+    {
+        const double dt = 0.2 - 0;
+        const double dt2 = dt / 2.0;
+        const double torque = (double)(action - 1);
+        double k1[4], k2[4], k3[4], k4[4], y[4];
+        dsdt(s, torque, k1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k1[i];
+        dsdt(y, torque, k2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k2[i];
+        dsdt(y, torque, k3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = s[i] + dt * k3[i];
+        dsdt(y, torque, k4);
+        double ns[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ns[i] = s[i] + dt / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        ns[0] = wrap(ns[0], -PI, PI);
+        ns[1] = wrap(ns[1], -PI, PI);
+        ns[2] = fmin(fmax(ns[2], -4 * PI), 4 * PI);
+        ns[3] = fmin(fmax(ns[3], -9 * PI), 9 * PI);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = ns[i];
+        const bool terminated = (-cos(ns[0]) - cos(ns[1] + ns[0]) > 1.0);
+        reward = terminated ? 0.0f : -1.0f;
+        write_obs(s, obs);
+        return terminated;
+    }
+};
+
+template <class Env> __device__ __forceinline__ void store_obs(float *dst, size_t n, const float (&obs)[6])
+{
+    if (Env::OBS == 4) {
+        *reinterpret_cast<float4 *>(dst + n * 4) = make_float4(obs[0], obs[1], obs[2], obs[3]);
+    } else {
+        float2 *p = reinterpret_cast<float2 *>(dst + n * 6);
+        p[0] = make_float2(obs[0], obs[1]);
+        p[1] = make_float2(obs[2], obs[3]);
+        p[2] = make_float2(obs[4], obs[5]);
+    }
+}
+
+__device__ __forceinline__ void draw_reset(const EnvArgs &a, size_t n, uint32_t episode, double (&u)[4])
+{
+    if (a.reset_draw) {
+        const double2 *p = reinterpret_cast<const double2 *>(a.reset_draw + n * 4);
+        const double2 lo = p[0], hi = p[1];
+        u[0] = lo.x; u[1] = lo.y; u[2] = hi.x; u[3] = hi.y;
+    } else {
+        reset_uniform4(a.seed, a.env_base + n, episode, u);
+    }
+}
+
+
+// Per-env registers carried across steps by the kernels.
+struct EnvRegs {
+    double s[4];
+    int elapsed;
+    float ep_ret;
+    int ep_len;
+};
+
+struct StepOut {
+    float obs[6];      // next observation (already the reset observation if the env was reset)
+    float term[6];     // terminal observation, valid when done + trunc > 0
+    float reward;
+    int done, trunc;
+};
+
+// One transition of env n.  Follows gymnasium env.step -> TimeLimit -> RecordEpisodeStatistics and
+// the actor loop of the reference's rollout (src/ppo.py:342-388).
+template <class Env>
+__device__ __forceinline__ void env_transition(EnvRegs &e, int action, const EnvArgs &a, size_t n, int is_last,
+                                               StepOut &o)
+{
+    const bool terminated = Env::step(e.s, action, o.obs, o.reward);
+    e.elapsed += 1;                                          // TimeLimit.step
+    const bool truncated = e.elapsed >= MAX_EPISODE_STEPS;
+    o.done = terminated ? 1 : 0;
+    o.trunc = truncated ? 1 : 0;
+
+    e.ep_ret += o.reward;                                    // RecordEpisodeStatistics.step
+    e.ep_len += 1;
+    const bool ended = terminated || truncated;
+    if (ended) {
+        if (a.ret_ring) {
+            const int c = a.ring_cnt[n];
+            const size_t slot = n * (size_t)a.ring + (size_t)(c % a.ring);
+            a.ret_ring[slot] = e.ep_ret;
+            a.len_ring[slot] = e.ep_len;
+            a.ring_cnt[n] = c + 1;
+        }
+        e.ep_ret = 0.0f;
+        e.ep_len = 0;
+    }
+    bool can_reset = true;
+    if (!ended && is_last) { o.trunc += 1; can_reset = false; }  // src/ppo.py:353-356
+    if (o.done + o.trunc > 0) {                              // src/ppo.py:377-382
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o.term[k] = o.obs[k];
+        if (can_reset) {
+            const uint32_t ep = a.episode[n];
+            double u[4];
+            draw_reset(a, n, ep, u);
+            Env::reset(e.s, u, o.obs);
+            a.episode[n] = ep + 1;
+            e.elapsed = 0;
+        }
+    }
+}
+
+__device__ __forceinline__ void load_env(EnvRegs &e, const EnvArgs &a, size_t n)
+{
+    const double2 *sp = reinterpret_cast<const double2 *>(a.state + n * 4);
+    const double2 s01 = sp[0], s23 = sp[1];
+    e.s[0] = s01.x; e.s[1] = s01.y; e.s[2] = s23.x; e.s[3] = s23.y;
+    e.elapsed = a.elapsed[n];
+    e.ep_ret = a.ep_ret[n];
+    e.ep_len = a.ep_len[n];
+}
+
+__device__ __forceinline__ void store_env(const EnvRegs &e, const EnvArgs &a, size_t n)
+{
+    double2 *sp = reinterpret_cast<double2 *>(a.state + n * 4);
+    sp[0] = make_double2(e.s[0], e.s[1]);
+    sp[1] = make_double2(e.s[2], e.s[3]);
+    a.elapsed[n] = e.elapsed;
+    a.ep_ret[n] = e.ep_ret;
+    a.ep_len[n] = e.ep_len;
+}
+
+// Categorical(logits) sample + log-prob for env `id` at policy step `step` (reference
+// src/ppo.py:186-189,212).  Key half 1 is offset so this stream never collides with the reset
+// stream of the same seed.
+__device__ __forceinline__ void categorical_sample(const float *lg, int A, uint64_t seed, uint64_t id, uint64_t step,
+                                                   int &action, float &logp)
+{
+    float mx = lg[0];
+    for (int k = 1; k < A; ++k) mx = fmaxf(mx, lg[k]);
+    float sum = 0.0f;
+    for (int k = 0; k < A; ++k) sum += expf(lg[k] - mx);
+    const float lse = mx + logf(sum);
+    const Philox4 rnd = philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)step, (uint32_t)(step >> 32),
+                                      (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
+    const float u = (float)(rnd.v[0] >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+    const float target = u * sum;
+    float cdf = 0.0f;
+    int pick = A - 1;
+    float lpick = lg[A - 1];
+    bool found = false;
+    for (int k = 0; k < A; ++k) {
+        cdf += expf(lg[k] - mx);
+        if (!found && target < cdf) { pick = k; lpick = lg[k]; found = true; }
+    }
+    action = pick;
+    logp = lpick - lse;
+}
+
+}  // namespace ppo_env

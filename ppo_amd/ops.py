@@ -179,3 +179,57 @@ def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int
     rc = lib.ppo_categorical_sample(_ptr(lg), A, seed, env_base, step, _ptr(action), _ptr(logp), N, _stream())
     _lib.check(rc, "ppo_categorical_sample")
     return action, logp
+
+
+# --------------------------------------------------------------------------- fused rollout
+def _mfma_frags(weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """Linear(K -> 64) as v_mfma_f32_32x32x2_f32 A-operand fragments [1 + K/2, 2, 64]
+    (layout documented at frag() in ppo_amd/csrc/rollout.hip)."""
+    W = weight.detach().to(torch.float32)
+    K = W.shape[1]
+    if K % 2:
+        W = torch.cat([W, W.new_zeros(64, 1)], dim=1)
+        K += 1
+    lane = torch.arange(64, device=W.device)
+    half, l31 = lane >> 5, lane & 31
+    frag = W.new_zeros(1 + K // 2, 2, 64)
+    for o in range(2):
+        frag[0, o] = torch.where(half == 0, bias.detach().to(torch.float32)[32 * o + l31], W.new_zeros(()))
+        s = torch.arange(K // 2, device=W.device)
+        frag[1:, o] = W[(32 * o + l31)[None, :], 2 * s[:, None] + half[None, :]]
+    return frag.reshape(-1)
+
+
+def pack_dense_agent(agent) -> torch.Tensor:
+    """Flatten a dense Agent's parameters into the layout k_rollout reads (rollout.hip): per
+    backbone the MFMA fragments of both tanh layers, then the heads as HP[64][4] (logit weights per
+    hidden unit, zero padded), bp[4], HV[64] (critic weights), bc[1]."""
+    def backbone(seq):
+        return [_mfma_frags(seq[0].weight, seq[0].bias), _mfma_frags(seq[2].weight, seq[2].bias)]
+    with torch.no_grad():
+        parts = backbone(agent.pi_backbone)
+        if not agent.joint_net:
+            parts += backbone(agent.va_backbone)
+        A = agent.policy.weight.shape[0]
+        hp = agent.policy.weight.new_zeros(64, 4)
+        hp[:, :A] = agent.policy.weight.t()
+        bp = agent.policy.bias.new_zeros(4)
+        bp[:A] = agent.policy.bias
+        parts += [hp.reshape(-1), bp, agent.critic.weight.reshape(-1), agent.critic.bias]
+        return torch.cat([p.detach().to(torch.float32).reshape(-1) for p in parts]).contiguous()
+
+
+def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, log_probs, values, rewards, done,
+                  trunc, term_obs, T):
+    """ppo_rollout_fused over a ppo_amd.envs.DeviceEnvBatch; every tensor is written in place."""
+    lib = _lib.load()
+    need = lib.ppo_rollout_param_floats(batch.kind, int(bool(joint)))
+    assert params.numel() == need and params.dtype == torch.float32 and params.is_cuda, (params.numel(), need)
+    rc = lib.ppo_rollout_fused(
+        batch.kind, batch.state.data_ptr(), batch.elapsed.data_ptr(), batch.ep_ret.data_ptr(),
+        batch.ep_len.data_ptr(), batch.episode.data_ptr(), None, batch.seed, batch.env_base, params.data_ptr(),
+        int(bool(joint)), int(sample_step0), obs_io.data_ptr(), states.data_ptr(), actions.data_ptr(),
+        log_probs.data_ptr(), values.data_ptr(), rewards.data_ptr(), done.data_ptr(), trunc.data_ptr(),
+        term_obs.data_ptr(), batch.ret_ring.data_ptr(), batch.len_ring.data_ptr(), batch.ring_cnt.data_ptr(),
+        batch.ring, batch.num_envs, int(T), _stream())
+    _lib.check(rc, "ppo_rollout_fused")

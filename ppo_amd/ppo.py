@@ -178,6 +178,9 @@ class SyncVecEnv:
         self.action_dtype = torch.int32 if spaces.is_discrete(self.action_space) else torch.float32
         self.device = agent.device
         self.fused_sampling = True  # device path: Categorical sample + log_prob in one kernel
+        # device path, dense net + Discrete head: the whole T-step rollout (policy forward, sampling,
+        # env transition) in ONE kernel launch.  False = PyTorch MLP + one env kernel per time step.
+        self.fused_rollout = True
         self._rollouts = 0
 
         first = env_fn()
@@ -270,7 +273,14 @@ class SyncVecEnv:
         carry = torch.empty((N, b.obs_dim), dtype=torch.float32, device=kdev)
         self.states[0].copy_(self.t_states)
         fused = self.fused_sampling and same and self.agent.discrete
-        for t in range(T):
+        whole = (self.fused_rollout and same and self.agent.discrete and not self.agent.conv_net
+                 and self.agent.action_space.n == ppo_envs.NUM_ACTIONS[b.kind])
+        if whole:
+            carry.copy_(self.t_states)
+            ops.rollout_fused(b, ops.pack_dense_agent(self.agent), self.agent.joint_net, self._rollouts * T, carry,
+                              self.states, self.actions, self.log_probs, self.values, self.rewards,
+                              self.done_flags, self.trunc_flags, self._term_obs, T)
+        for t in range(0 if whole else T):
             obs = self.states[t] if same else self.states[t].to(adev)
             if fused:
                 logits, values = self.agent.policy_and_values(obs)

@@ -53,8 +53,10 @@ def test_vec_env_rollout(device):
     assert vec_env.global_steps == 250 and vec_env.total_return == np.float32(250.0)
 
 
+@pytest.mark.parametrize("whole", [False, True], ids=["per_step_kernels", "whole_rollout_kernel"])
+@pytest.mark.parametrize("joint", [1, 0], ids=["joint", "split"])
 @pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
-def test_device_rollout_matches_serial_reference_loop(kind):
+def test_device_rollout_matches_serial_reference_loop(kind, joint, whole):
     """Same policy, same sampled actions (replayed), same reset draws (Philox): the fused device
     rollout and the oracle's restatement of the reference's serial loop (src/ppo.py:320-402) give
     the same buffers -- flags exact, the rest to f32 tolerance -- over two consecutive rollouts."""
@@ -63,8 +65,13 @@ def test_device_rollout_matches_serial_reference_loop(kind):
     torch.manual_seed(0)
     N, T, seed = 64, 96, 2024
     probe = DeviceEnv(kind)
-    agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
+    agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=joint, device="cuda")
+    with torch.no_grad():  # away from the near-uniform init so that log-probs / values are non-trivial
+        agent.policy.weight.mul_(60.0)
+        agent.policy.bias.uniform_(-0.5, 0.5)
+        agent.critic.bias.fill_(0.3)
     ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=seed), N, T, 0, 0.0, agent, seed=seed)
+    ve.fused_rollout = whole
 
     ora = cref.BatchEnv(kind, N, seed=seed)
     t_states = torch.from_numpy(ora.reset())
@@ -110,10 +117,20 @@ def test_device_rollout_matches_serial_reference_loop(kind):
         assert torch.allclose(ve.end_states.cpu(), ref["end_states"], rtol=1e-5, atol=1e-6)
         assert torch.allclose(ve.t_states.cpu(), t_states, rtol=1e-5, atol=1e-6)
         # the policy outputs recorded by the fused sampler are consistent with the agent
+        # policy outputs recorded by the rollout vs the PyTorch forward of the same agent on the
+        # recorded states (all T*N samples): 1e-5 relative, abs floor 2e-6 (f32 summation order)
         with torch.no_grad():
-            logits, vals = agent.policy_and_values(ve.states.detach()[5])
-        lp = torch.log_softmax(logits, 1).gather(1, ve.actions[5].long()[:, None])[:, 0]
-        assert torch.allclose(lp, ve.log_probs[5], rtol=1e-5, atol=1e-6) and torch.allclose(vals, ve.values[5])
+            logits, vals = agent.policy_and_values(ve.states.detach().flatten(0, 1))
+        lp = torch.log_softmax(logits, 1).gather(1, ve.actions.flatten().long()[:, None])[:, 0]
+        assert torch.allclose(lp, ve.log_probs.flatten(), rtol=1e-5, atol=2e-6)
+        assert torch.allclose(vals, ve.values.flatten(), rtol=1e-5, atol=2e-6)
+        # and the sampled actions are the Philox draw applied to those logits
+        from ppo_amd import ops
+        for t in (0, T // 2, T - 1):
+            with torch.no_grad():
+                lg, _ = agent.policy_and_values(ve.states.detach()[t])
+            a_ref, _ = ops.categorical_sample(lg, seed, 0, k * T + t)
+            assert (a_ref == ve.actions[t]).float().mean() > 0.98  # an ulp in a logit may flip a boundary draw
         assert int(ref["done"].sum()) > 0 or kind == "acrobot"
 
 
