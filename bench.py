@@ -17,6 +17,7 @@ star sets a target for), timed with HIP events on the launch stream inside the t
 (oracle/pyref.py, kind "port"), timed on rank 0 at N=1 on a bounded sample.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -36,7 +37,7 @@ GAE_BYTES_PER_ELEM = 20        # r, v, done, trunc read + adv written; the end v
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--env", default="cartpole", choices=["cartpole", "acrobot"])
     p.add_argument("--num-envs", type=int, default=65536, help="envs PER GPU")
@@ -82,7 +83,8 @@ def cpu_baseline(kind, n_envs, T, seed):
 
 def main():
     args = parse()
-    from ppo_amd import PPO, Agent, SyncVecEnv, ops
+    from ppo_amd import PPO, Agent, SyncVecEnv, ops, _lib
+    lib = _lib.load()
     from ppo_amd import dist as D
     from ppo_amd.envs import DeviceEnv
 
@@ -110,20 +112,19 @@ def main():
     def hot_path_step(record):
         ve.rollout()
         with torch.no_grad():
-            end_values = agent.get_values(ve.end_states)
-            ev_dense = ppo._scatter_end_values(ve, end_values)
+            if ve._ev_ready:                       # whole-rollout kernel wrote V(terminal obs) itself
+                ev_dense = ve._ev_dense
+            else:
+                ev_dense = ppo._scatter_end_values(ve, agent.get_values(ve.end_states))
+            record = record and len(gae_events) < 256   # ppo_prof_* has 256 slots
             if record:
-                # The host has just synchronised (end_states size), so the GPU is idle and an event
-                # pair would also time the host's launch latency.  A ~40 us on-GPU spin queued FIRST
-                # lets the host run ahead; e0 then fires when the spin ends and the GAE kernel is
-                # already in the queue, so e1 - e0 is the kernel's duration (agrees with rocprofv3).
-                torch.cuda._sleep(100_000)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                # hipExtLaunchKernelGGL start/stop events on the GAE dispatch itself (ppo_prof_* in
+                # csrc/gae.hip); read back after the timed region.  Agrees with rocprofv3 --kernel-trace.
+                slot = len(gae_events)
+                _lib.check(lib.ppo_prof_arm(slot), "ppo_prof_arm")
             adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95)
             if record:
-                e1.record()
-                gae_events.append((e0, e1, int((ve.trunc_flags != 0).sum())))
+                gae_events.append((slot, (ve.trunc_flags != 0).sum()))
         return adv
 
     def barrier():
@@ -144,8 +145,13 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    gae_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in gae_events]))
-    n_trunc = float(np.mean([n for _, _, n in gae_events]))
+    us = C.c_float()
+    gae_us = []
+    for slot, _ in gae_events:
+        _lib.check(lib.ppo_prof_elapsed_us(slot, C.byref(us)), "ppo_prof_elapsed_us")
+        gae_us.append(us.value)
+    gae_ms = float(np.mean(gae_us)) * 1e-3
+    n_trunc = float(np.mean([int(n) for _, n in gae_events]))
     gae_bytes = int(GAE_BYTES_PER_ELEM * T * N + 4 * n_trunc)
     achieved = gae_bytes / (gae_ms * 1e-3) / 1e9
     traffic = None
@@ -163,7 +169,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 env state / f32 buffers", "data": "synthetic",
             "config": {"workload": f"{kind} batched stepping + GAE, N={N} envs/GPU x T={T}, dense 64-64 tanh policy "
-                                   f"(joint net) on PyTorch-ROCm, BASELINE configs[1]",
+                                   f"(joint net, f32) inside the whole-rollout kernel, BASELINE configs[1]",
                        "num_envs_per_gpu": N, "rollout_len": T, "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "k_gae (ppo_gae_dense)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -170,6 +170,9 @@ size_t ppo_rollout_param_floats(int kind, int joint);
  *   obs_io      [N,obs_dim] f32: current observations in, carried observations out (:398)
  *   states [T,N,obs_dim] f32, actions [T,N] i32, log_probs/values/rewards [T,N] f32,
  *   done/trunc [T,N] i32, term_obs [T,N,obs_dim] f32 (written where done+trunc > 0)
+ *   ev_dense [T,N] f32 or NULL: the critic's value of the terminal observation, written where
+ *   trunc != 0 -- the end_value_dense input of ppo_gae_dense, i.e. what the reference computes
+ *   with agent.get_values(end_states) (src/ppo.py:555) and reads where trunc != 0 (:478)
  * Env state arguments and rings as in ppo_env_step; row T-1 gets the forced truncation.
  * Network arithmetic is f32 FMA; values / log-probs agree with the PyTorch forward of the same
  * parameters to ~1e-6 (different summation order than hipBLASLt), not bit for bit.
@@ -178,8 +181,9 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
                       uint32_t *episode, const double *reset_draw, uint64_t seed,
                       uint64_t env_base, const float *params, int joint, uint64_t sample_step0,
                       float *obs_io, float *states, int *actions, float *log_probs, float *values,
-                      float *rewards, int *done, int *trunc, float *term_obs, float *ret_ring,
-                      int *len_ring, int *ring_cnt, int ring, int N, int T, void *stream);
+                      float *rewards, int *done, int *trunc, float *term_obs, float *ev_dense,
+                      float *ret_ring, int *len_ring, int *ring_cnt, int ring, int N, int T,
+                      void *stream);
 
 #ifdef __cplusplus
 }

@@ -27,12 +27,14 @@ SIGNATURES = {
     "ppo_categorical_sample": (_i, [_vp, _i, _u64, _u64, _u64, _vp, _vp, _i, _vp]),
     "ppo_rollout_param_floats": (_sz, [_i, _i]),
     "ppo_rollout_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _u64, _vp, _vp, _vp, _vp,
-                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 # tuning hook, deliberately not in the public header
 _PRIVATE = {
     "ppo_gae_dense_variant": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_stream_ceiling": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
+    "ppo_prof_arm": (_i, [_i]),
+    "ppo_prof_elapsed_us": (_i, [_i, C.POINTER(C.c_float)]),
 }
 
 _lib = None

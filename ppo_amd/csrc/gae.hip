@@ -16,8 +16,19 @@
 // (the library is built with -ffp-contract=off), so results are bit-identical to
 // torch-CPU for flags in {0,1} and reproduce its (1 - terminations) arithmetic otherwise.
 #include "common.h"
+#include <hip/hip_ext.h>
 
 namespace {
+
+// Bench-only kernel timing (private symbols ppo_prof_*; not part of include/ppo_amd.h): an armed
+// slot makes the NEXT GAE launch go through hipExtLaunchKernelGGL with a start/stop event pair,
+// which timestamps the dispatch packet itself.  A plain hipEventRecord pair around the launch
+// also times two barrier packets (+25..50 us on this stack), rocprofv3 agrees with this form.
+constexpr int PROF_SLOTS = 256;
+hipEvent_t g_prof_start[PROF_SLOTS], g_prof_stop[PROF_SLOTS];
+bool g_prof_have[PROF_SLOTS];
+int g_prof_armed = -1;
+
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using F = float; using I = int; };
@@ -261,6 +272,13 @@ template <int VEC, int U> int launch_gae_sparse(const GaeArgs &a, hipStream_t s)
     const long waves = (threads + 63) / 64;
     const int block = waves <= 2048 ? 64 : 256;
     const long grid = (threads + block - 1) / block;
+    if (g_prof_armed >= 0) {
+        const int slot = g_prof_armed;
+        g_prof_armed = -1;
+        hipExtLaunchKernelGGL((k_gae_sparse<VEC, U>), dim3((unsigned)grid), dim3(block), 0, s, g_prof_start[slot],
+                              g_prof_stop[slot], 0, a);
+        return ppo_launch_status();
+    }
     hipLaunchKernelGGL((k_gae_sparse<VEC, U>), dim3((unsigned)grid), dim3(block), 0, s, a);
     return ppo_launch_status();
 }
@@ -401,6 +419,31 @@ int ppo_gae_dense(const float *rewards, const float *values, const float *end_va
                       ppo_aligned(adv, 8) && (!ret || ppo_aligned(ret, 8));
     return ppo_gae_dense_variant(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
                                  vec2 ? 5 : 3, stream);
+}
+
+// Bench-only: time the next GAE launch into `slot` / read a finished slot back (waits for it).
+int ppo_prof_arm(int slot)
+{
+    PPO_REQUIRE(slot >= 0 && slot < PROF_SLOTS);
+    if (!g_prof_have[slot]) {
+        hipError_t e = hipEventCreate(&g_prof_start[slot]);
+        if (e == hipSuccess) e = hipEventCreate(&g_prof_stop[slot]);
+        if (e != hipSuccess) return (int)e;
+        g_prof_have[slot] = true;
+    }
+    g_prof_armed = slot;
+    return 0;
+}
+
+int ppo_prof_elapsed_us(int slot, float *us)
+{
+    PPO_REQUIRE(slot >= 0 && slot < PROF_SLOTS && g_prof_have[slot] && us);
+    hipError_t e = hipEventSynchronize(g_prof_stop[slot]);
+    if (e != hipSuccess) return (int)e;
+    float ms = 0.0f;
+    e = hipEventElapsedTime(&ms, g_prof_start[slot], g_prof_stop[slot]);
+    *us = ms * 1000.0f;
+    return (int)e;
 }
 
 // Tuning hook: streaming ceiling with the GAE traffic mix (n elements, 16-byte aligned, n % 4 == 0).

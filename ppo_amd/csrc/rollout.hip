@@ -43,6 +43,7 @@ struct RolloutArgs {
     float *log_probs, *values, *rewards;  // [T,N]
     int *done, *trunc;       // [T,N]
     float *term_obs;         // [T,N,OBS], written where a flag is raised
+    float *ev_dense;         // [T,N] or NULL: V(terminal obs) written where trunc != 0
     int T;
 };
 
@@ -188,6 +189,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         categorical_sample(lg, A, a.env.seed, a.env.env_base + nn, a.sample_step0 + (uint64_t)t, action, logp);
 
         StepOut o;
+        o.trunc = 0;
         if (live) {
             env_transition<Env>(e, action, a.env, nn, t == a.T - 1, o);
             const size_t row = (size_t)t * N + n;
@@ -199,6 +201,23 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
             a.done[row] = o.done;
             a.trunc[row] = o.trunc;
             if (o.done + o.trunc > 0) store_obs<Env>(a.term_obs, row, o.term);
+        }
+        // ---- bootstrap value of the terminal observation for truncated episodes: what the
+        // reference gets from agent.get_values(end_states) (src/ppo.py:555) and uses where
+        // trunc != 0 (:478).  Wave-uniform branch: taken when any of the 64 envs truncated (always
+        // at the forced last step, ~1/8 of the other steps for a policy that reaches the 500-step limit).
+        const bool need_ev = a.ev_dense != nullptr && live && o.trunc > 0;
+        if (__any(need_ev)) {
+#pragma unroll
+            for (int k = 0; k < OBS; ++k) hl[k * 64] = need_ev ? o.term[k] : obs[k];
+            dense_tanh_mfma<OBS>(hw, JOINT ? F1 : G1, lane);
+            dense_tanh_mfma<H>(hw, JOINT ? F2 : G2, lane);
+            float ev = bc[0];
+#pragma unroll 8
+            for (int k = 0; k < H; ++k) ev = __builtin_fmaf(hl[k * 64], HV[k], ev);
+            if (need_ev) a.ev_dense[(size_t)t * N + n] = ev;
+        }
+        if (live) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) obs[k] = o.obs[k];
         }
@@ -234,7 +253,7 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
                       const double *reset_draw, uint64_t seed, uint64_t env_base, const float *params,
                       int joint, uint64_t sample_step0, float *obs_io, float *states, int *actions,
                       float *log_probs, float *values, float *rewards, int *done, int *trunc, float *term_obs,
-                      float *ret_ring, int *len_ring, int *ring_cnt, int ring, int N, int T, void *stream)
+                      float *ev_dense, float *ret_ring, int *len_ring, int *ring_cnt, int ring, int N, int T, void *stream)
 {
     PPO_REQUIRE(kind == PPO_ENV_CARTPOLE || kind == PPO_ENV_ACROBOT);
     PPO_REQUIRE(N >= 0 && T >= 0);
@@ -254,7 +273,7 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
     a.env.N = N;
     a.params = params; a.sample_step0 = sample_step0; a.obs_io = obs_io; a.states = states; a.actions = actions;
     a.log_probs = log_probs; a.values = values; a.rewards = rewards; a.done = done; a.trunc = trunc;
-    a.term_obs = term_obs; a.T = T;
+    a.term_obs = term_obs; a.ev_dense = ev_dense; a.T = T;
     hipStream_t s = (hipStream_t)stream;
     if (kind == PPO_ENV_CARTPOLE) return launch_rollout<CartPole, 2>(a, joint, s);
     return launch_rollout<Acrobot, 3>(a, joint, s);

@@ -171,9 +171,16 @@ class SyncVecEnv:
             print("ppo_amd: GIF rendering is out of scope for device-resident envs; render_every ignored")
         self.render_every, self.render_fps = (render_every if render_every > 0 else 1), render_fps
         self.agent = agent
+        # episode statistics (reference src/ppo.py:250-254): host values, or a device tensor that is
+        # fetched on first read (see the properties below) so that a rollout never waits on the host
         nan = np.float32(np.nan)
-        self.max_ep_return = self.lower_ep_return = self.median_ep_return = nan
-        self.upper_ep_return = self.median_ep_length = nan
+        self._stats_host = {"max": nan, "lower": nan, "median": nan, "upper": nan, "length": nan}
+        self._stats_dev = None
+        self._run_max_dev = None
+        self._stats_stream = None
+        self._packed = (None, None)
+        self._total_return = np.float32(0.0)
+        self._end_states = None
         self.state_space, self.action_space = agent.state_space, agent.action_space
         self.action_dtype = torch.int32 if spaces.is_discrete(self.action_space) else torch.float32
         self.device = agent.device
@@ -275,11 +282,15 @@ class SyncVecEnv:
         fused = self.fused_sampling and same and self.agent.discrete
         whole = (self.fused_rollout and same and self.agent.discrete and not self.agent.conv_net
                  and self.agent.action_space.n == ppo_envs.NUM_ACTIONS[b.kind])
+        self._ev_ready = False
         if whole:
+            if self._ev_dense is None or self._ev_dense.shape != self.rewards.shape:
+                self._ev_dense = torch.empty_like(self.rewards)
             carry.copy_(self.t_states)
-            ops.rollout_fused(b, ops.pack_dense_agent(self.agent), self.agent.joint_net, self._rollouts * T, carry,
+            ops.rollout_fused(b, self._packed_params(), self.agent.joint_net, self._rollouts * T, carry,
                               self.states, self.actions, self.log_probs, self.values, self.rewards,
-                              self.done_flags, self.trunc_flags, self._term_obs, T)
+                              self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T)
+            self._ev_ready = True                      # bootstrap values already written by the kernel
         for t in range(0 if whole else T):
             obs = self.states[t] if same else self.states[t].to(adev)
             if fused:
@@ -297,18 +308,118 @@ class SyncVecEnv:
                    self.trunc_flags[t], is_last=(t == T - 1))
         self.global_steps += T * N
         self.t_states = carry if same else carry.to(adev)
-
-        # end_states: terminal observations, actor-major / time-ascending (reference :401-402)
-        ended = (self.done_flags + self.trunc_flags) > 0
-        nt = ended.t().nonzero()                       # one host sync per rollout (size E)
-        self._end_n, self._end_t = nt[:, 0], nt[:, 1]
-        self.end_states = self._term_obs[self._end_t, self._end_n]
-        self.total_return = np.float32(self.rewards.sum(dtype=torch.float32).item())
+        self._end_states = self._end_n = self._end_t = None   # built on first access (end_states property)
+        self._total_return = self.rewards.sum(dtype=torch.float32)   # device scalar, fetched on read
         if not same:
+            self._locate_end_states()
             for name in ("states", "actions", "rewards", "done_flags", "trunc_flags", "values", "log_probs",
-                         "end_states"):
+                         "_end_states"):
                 setattr(self, name, getattr(self, name).to(adev))
-        self._episode_percentiles(*b.episode_stats())
+        self._device_episode_stats()
+
+    def _packed_params(self) -> torch.Tensor:
+        """Network in the whole-rollout kernel's layout; repacked only when a parameter changed
+        (torch bumps a tensor's _version on every in-place update, i.e. on every optimiser step)."""
+        key = tuple((id(p), p._version) for p in self.agent.parameters())
+        if self._packed[0] != key:
+            self._packed = (key, ops.pack_dense_agent(self.agent))
+        return self._packed[1]
+
+    def _locate_end_states(self):
+        """end_states: terminal observations, actor-major / time-ascending (reference :401-402).
+        Costs one host sync (the count E), so it is built only when somebody asks for it."""
+        ended = (self.done_flags.to(self.kdev) + self.trunc_flags.to(self.kdev)) > 0
+        nt = ended.t().nonzero()
+        self._end_n, self._end_t = nt[:, 0], nt[:, 1]
+        self._end_states = self._term_obs[self._end_t, self._end_n]
+
+    @property
+    def end_states(self):
+        if self._end_states is None and self.native:
+            self._locate_end_states()
+        return self._end_states
+
+    @end_states.setter
+    def end_states(self, value):
+        self._end_states = value
+
+    @property
+    def total_return(self):
+        if isinstance(self._total_return, torch.Tensor):
+            self._total_return = np.float32(self._total_return.item())
+        return self._total_return
+
+    @total_return.setter
+    def total_return(self, value):
+        self._total_return = value
+
+    def _device_episode_stats(self):
+        """reference src/ppo.py:407-417 on the device rings, without a host round trip: running max,
+        5/50/95 percentiles (np.percentile 'linear') of the last <=100 returns of every env, median
+        length.  Result stays a device tensor until one of the statistics attributes is read."""
+        b = self.batch
+        dev = b.device
+        # Snapshot the rings on the rollout's stream, then do the order statistics on a side stream:
+        # the whole-rollout kernel runs one wave per SIMD and leaves most of the chip's issue slots and
+        # bandwidth idle, so the sorts overlap with the GAE / next rollout instead of extending the step.
+        main = torch.cuda.current_stream()
+        if self._stats_stream is None:
+            self._stats_stream = torch.cuda.Stream(device=dev)
+        snap_ret, snap_len, snap_cnt = b.ret_ring.clone(), b.len_ring.clone(), b.ring_cnt.clone()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._stats_stream):
+            self._stats_stream.wait_event(ready)
+            for x in (snap_ret, snap_len, snap_cnt):
+                x.record_stream(self._stats_stream)
+            cnt = snap_cnt.clamp(max=b.ring)
+            n = cnt.sum()
+            valid = torch.arange(b.ring, device=dev)[None, :] < cnt[:, None]
+            inf = torch.tensor(float("inf"), device=dev)
+            rets = torch.sort(torch.where(valid, snap_ret, inf).flatten()).values
+            lens = torch.sort(torch.where(valid, snap_len.to(torch.float32), inf).flatten()).values
+            nm1 = (n - 1).clamp(min=0)
+            q = torch.tensor([0.05, 0.5, 0.95, 1.0], dtype=torch.float64, device=dev)
+            pos = q * nm1.to(torch.float64)
+            lo = pos.floor().long()
+            hi = torch.minimum(lo + 1, nm1)
+            frac = pos - lo.to(torch.float64)
+            r_lo, r_hi = rets[lo].to(torch.float64), rets[hi].to(torch.float64)
+            pr = r_lo + (r_hi - r_lo) * frac                       # p5, p50, p95, max
+            l_lo, l_hi = lens[lo[1]].to(torch.float64), lens[hi[1]].to(torch.float64)
+            med_len = l_lo + (l_hi - l_lo) * frac[1]
+            cur_max = pr[3]
+            if self._run_max_dev is None:
+                self._run_max_dev = torch.full((), float("-inf"), dtype=torch.float64, device=dev)
+            self._run_max_dev = torch.where(n > 0, torch.maximum(self._run_max_dev, cur_max), self._run_max_dev)
+            nan = torch.tensor(float("nan"), dtype=torch.float64, device=dev)
+            run_max = torch.where(torch.isinf(self._run_max_dev), nan, self._run_max_dev)
+            stats = torch.stack([run_max, pr[0], pr[1], pr[2], med_len])
+            self._stats_dev = torch.where(n > 0, stats, torch.stack([run_max, nan, nan, nan, nan]))
+
+    def _stat(self, key):
+        if self._stats_dev is not None:                 # one device->host copy for all five values
+            with torch.cuda.stream(self._stats_stream):
+                v = self._stats_dev.cpu().numpy()
+            self._stats_dev = None
+            prev = self._stats_host
+            self._stats_host = {"max": np.float32(v[0]),
+                                "lower": v[1] if not np.isnan(v[1]) else prev["lower"],
+                                "median": v[2] if not np.isnan(v[2]) else prev["median"],
+                                "upper": v[3] if not np.isnan(v[3]) else prev["upper"],
+                                "length": v[4] if not np.isnan(v[4]) else prev["length"]}
+        return self._stats_host[key]
+
+    max_ep_return = property(lambda self: self._stat("max"),
+                             lambda self, v: self._stats_host.__setitem__("max", v))
+    lower_ep_return = property(lambda self: self._stat("lower"),
+                               lambda self, v: self._stats_host.__setitem__("lower", v))
+    median_ep_return = property(lambda self: self._stat("median"),
+                                lambda self, v: self._stats_host.__setitem__("median", v))
+    upper_ep_return = property(lambda self: self._stat("upper"),
+                               lambda self, v: self._stats_host.__setitem__("upper", v))
+    median_ep_length = property(lambda self: self._stat("length"),
+                                lambda self, v: self._stats_host.__setitem__("length", v))
 
     def _rollout_host(self):
         """Host-stepped gym envs; the control flow of reference src/ppo.py:320-398 with the
@@ -343,6 +454,7 @@ class SyncVecEnv:
         self.total_return = total
         self.end_states = torch.cat([torch.stack(e, dim=0) for e in end_states], dim=0).to(dev)
         self._end_n = self._end_t = None
+        self._ev_ready = False
         if not hasattr(self.envs[0], "return_queue"):  # reference :404-405
             return
         rets = np.concatenate([np.array(e.return_queue, dtype=np.float64).reshape(-1) for e in self.envs])
@@ -418,8 +530,7 @@ class PPO:
         rollout_start = time.time()
         ve.rollout()
         with torch.no_grad():
-            end_values = self.agent.get_values(ve.end_states)
-            advantages = self._advantages(ve, end_values)
+            advantages = self._rollout_advantages(ve)
         _sync()
         rollout_time = time.time() - rollout_start
         env_steps_per_sec = steps_per_env * num_envs * world / rollout_time
@@ -505,6 +616,14 @@ class PPO:
         }
         self._log(self.last_metrics, step=self.updates * steps_per_env * num_envs * world)
         return policy_loss, critic_loss, entropy, clip_frac, kl_div, rollout_return, ep_return_max
+
+    def _rollout_advantages(self, ve: SyncVecEnv) -> torch.Tensor:
+        """Bootstrap values + GAE for the rollout just collected (reference src/ppo.py:554-557)."""
+        if getattr(ve, "_ev_ready", False):   # whole-rollout kernel already wrote V(terminal obs) where trunc != 0
+            return ops.gae_dense(ve.rewards, ve.values, ve._ev_dense, ve.done_flags, ve.trunc_flags,
+                                 self.discount_factor, self.gae_factor)
+        end_values = self.agent.get_values(ve.end_states)
+        return self._advantages(ve, end_values)
 
     def _scatter_end_values(self, ve: SyncVecEnv, end_values: torch.Tensor) -> torch.Tensor:
         """Dense bootstrap buffer: V(terminal obs) written at the (t, n) that raised the flag.  Only
