@@ -95,8 +95,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: ppo_amd has no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    backend = os.environ.get("PPO_AMD_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on a 1-GPU box
     if world > 1:
-        D.init_from_env("nccl")
+        D.init_from_env(backend)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     N, T, kind = args.num_envs, args.rollout_len, args.env
@@ -104,7 +105,8 @@ def main():
     ppo = PPO(0.99, 0.95, 1, 1, 0, 1, True, seed=args.seed)
     probe = DeviceEnv(kind)
     ppo.agent = agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
-    D.broadcast_params(agent)
+    if backend == "nccl":
+        D.broadcast_params(agent)   # same policy on every rank (RCCL); the rollout itself needs no collective
     ppo.vec_env = ve = SyncVecEnv(lambda: DeviceEnv(kind), N, T, 0, 0.0, agent, seed=args.seed, env_base=rank * N)
 
     gae_events = []
@@ -141,7 +143,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
