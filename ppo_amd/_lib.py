@@ -25,6 +25,8 @@ SIGNATURES = {
     "ppo_adv_stats": (_i, [_vp, _l, _vp, _vp, _sz, _vp]),
     "ppo_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _l, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ppo_categorical_sample": (_i, [_vp, _i, _u64, _u64, _u64, _vp, _vp, _i, _vp]),
+    "ppo_episode_keys": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "ppo_episode_stats": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "ppo_rollout_param_floats": (_sz, [_i, _i]),
     "ppo_rollout_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _u64, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -26,6 +26,7 @@
 // Bound: MFMA issue (144 x 64 cycles per step, joint net) + ~2k VALU instructions per step.
 // HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done, trunc).
 #include "env_core.h"
+#include <cstdlib>
 
 using namespace ppo_env;
 
@@ -45,6 +46,7 @@ struct RolloutArgs {
     float *term_obs;         // [T,N,OBS], written where a flag is raised
     float *ev_dense;         // [T,N] or NULL: V(terminal obs) written where trunc != 0
     int T;
+    int ablate;              // diagnostic only (PPO_ROLLOUT_ABLATE): 1 skip network, 2 skip physics, 4 skip sampling
 };
 
 // Packed parameter layout (floats), built by ppo_amd.ops.pack_dense_agent:
@@ -159,8 +161,10 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         // ---- policy backbone (src/ppo.py:126-131) on the matrix cores
 #pragma unroll
         for (int k = 0; k < OBS; ++k) hl[k * 64] = obs[k];
-        dense_tanh_mfma<OBS>(hw, F1, lane);
-        dense_tanh_mfma<H>(hw, F2, lane);
+        if (!(a.ablate & 1)) {
+            dense_tanh_mfma<OBS>(hw, F1, lane);
+            dense_tanh_mfma<H>(hw, F2, lane);
+        }
 
         // ---- heads (:140, :145): lane = env again, 64-term fmaf chains in unit order
         float lg[A], value = bc[0];
@@ -186,12 +190,24 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 
         int action;
         float logp;
-        categorical_sample(lg, A, a.env.seed, a.env.env_base + nn, a.sample_step0 + (uint64_t)t, action, logp);
+        if (!(a.ablate & 4)) {
+            categorical_sample(lg, A, a.env.seed, a.env.env_base + nn, a.sample_step0 + (uint64_t)t, action, logp);
+        } else {
+            action = lg[0] > lg[1]; logp = lg[0];
+        }
 
         StepOut o;
         o.trunc = 0;
         if (live) {
-            env_transition<Env>(e, action, a.env, nn, t == a.T - 1, o);
+            if (!(a.ablate & 2)) {
+                env_transition<Env>(e, action, a.env, nn, t == a.T - 1, o);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o.obs[k] = obs[k] + 1e-3f * (float)action;
+                o.reward = 1.0f; o.done = 0; o.trunc = (t == a.T - 1);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o.term[k] = o.obs[k];
+            }
             const size_t row = (size_t)t * N + n;
             store_obs<Env>(a.states, row, obs);        // pre-step observation (src/ppo.py:390)
             a.actions[row] = action;
@@ -274,6 +290,8 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
     a.params = params; a.sample_step0 = sample_step0; a.obs_io = obs_io; a.states = states; a.actions = actions;
     a.log_probs = log_probs; a.values = values; a.rewards = rewards; a.done = done; a.trunc = trunc;
     a.term_obs = term_obs; a.ev_dense = ev_dense; a.T = T;
+    const char *abl = getenv("PPO_ROLLOUT_ABLATE");
+    a.ablate = abl ? atoi(abl) : 0;
     hipStream_t s = (hipStream_t)stream;
     if (kind == PPO_ENV_CARTPOLE) return launch_rollout<CartPole, 2>(a, joint, s);
     return launch_rollout<Acrobot, 3>(a, joint, s);

@@ -176,7 +176,6 @@ class SyncVecEnv:
         nan = np.float32(np.nan)
         self._stats_host = {"max": nan, "lower": nan, "median": nan, "upper": nan, "length": nan}
         self._stats_dev = None
-        self._run_max_dev = None
         self._stats_stream = None
         self._packed = (None, None)
         self._total_return = np.float32(0.0)
@@ -359,55 +358,38 @@ class SyncVecEnv:
         length.  Result stays a device tensor until one of the statistics attributes is read."""
         b = self.batch
         dev = b.device
-        # Snapshot the rings on the rollout's stream, then do the order statistics on a side stream:
-        # the whole-rollout kernel runs one wave per SIMD and leaves most of the chip's issue slots and
-        # bandwidth idle, so the sorts overlap with the GAE / next rollout instead of extending the step.
+        lib = ops._lib.load()
+        # ppo_episode_keys snapshots the rings on the rollout's stream (so the next rollout may overwrite
+        # them); the sorts and ppo_episode_stats then run on a side stream: the whole-rollout kernel runs
+        # one wave per SIMD and leaves most of the chip's bandwidth idle, so they overlap with GAE and the
+        # next rollout instead of extending the step.  Four host calls in total.
         main = torch.cuda.current_stream()
         if self._stats_stream is None:
             self._stats_stream = torch.cuda.Stream(device=dev)
-        snap_ret, snap_len, snap_cnt = b.ret_ring.clone(), b.len_ring.clone(), b.ring_cnt.clone()
-        ready = torch.cuda.Event()
-        ready.record(main)
-        with torch.cuda.stream(self._stats_stream):
-            self._stats_stream.wait_event(ready)
-            for x in (snap_ret, snap_len, snap_cnt):
-                x.record_stream(self._stats_stream)
-            cnt = snap_cnt.clamp(max=b.ring)
-            n = cnt.sum()
-            valid = torch.arange(b.ring, device=dev)[None, :] < cnt[:, None]
-            inf = torch.tensor(float("inf"), device=dev)
-            rets = torch.sort(torch.where(valid, snap_ret, inf).flatten()).values
-            lens = torch.sort(torch.where(valid, snap_len.to(torch.float32), inf).flatten()).values
-            nm1 = (n - 1).clamp(min=0)
-            q = torch.tensor([0.05, 0.5, 0.95, 1.0], dtype=torch.float64, device=dev)
-            pos = q * nm1.to(torch.float64)
-            lo = pos.floor().long()
-            hi = torch.minimum(lo + 1, nm1)
-            frac = pos - lo.to(torch.float64)
-            r_lo, r_hi = rets[lo].to(torch.float64), rets[hi].to(torch.float64)
-            pr = r_lo + (r_hi - r_lo) * frac                       # p5, p50, p95, max
-            l_lo, l_hi = lens[lo[1]].to(torch.float64), lens[hi[1]].to(torch.float64)
-            med_len = l_lo + (l_hi - l_lo) * frac[1]
-            cur_max = pr[3]
-            if self._run_max_dev is None:
-                self._run_max_dev = torch.full((), float("-inf"), dtype=torch.float64, device=dev)
-            self._run_max_dev = torch.where(n > 0, torch.maximum(self._run_max_dev, cur_max), self._run_max_dev)
-            nan = torch.tensor(float("nan"), dtype=torch.float64, device=dev)
-            run_max = torch.where(torch.isinf(self._run_max_dev), nan, self._run_max_dev)
-            stats = torch.stack([run_max, pr[0], pr[1], pr[2], med_len])
-            self._stats_dev = torch.where(n > 0, stats, torch.stack([run_max, nan, nan, nan, nan]))
+            self._stats5 = torch.full((5,), float("nan"), dtype=torch.float64, device=dev)
+            self._stats_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._stats_keys = torch.empty((2, b.num_envs * b.ring), dtype=torch.float32, device=dev)
+        st = self._stats_stream
+        main.wait_stream(st)                            # previous statistics pass is done with the key buffers
+        keys = self._stats_keys
+        ops._lib.check(lib.ppo_episode_keys(b.ret_ring.data_ptr(), b.len_ring.data_ptr(), b.ring_cnt.data_ptr(),
+                                            b.ring, b.num_envs, keys[0].data_ptr(), keys[1].data_ptr(),
+                                            self._stats_cnt.data_ptr(), main.cuda_stream), "ppo_episode_keys")
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            srt = torch.sort(keys, dim=1).values        # one segmented radix sort for both key arrays
+            srt.record_stream(st)
+            ops._lib.check(lib.ppo_episode_stats(srt[0].data_ptr(), srt[1].data_ptr(), self._stats_cnt.data_ptr(),
+                                                 self._stats5.data_ptr(), st.cuda_stream), "ppo_episode_stats")
+        self._stats_dev = self._stats5
 
     def _stat(self, key):
         if self._stats_dev is not None:                 # one device->host copy for all five values
             with torch.cuda.stream(self._stats_stream):
                 v = self._stats_dev.cpu().numpy()
             self._stats_dev = None
-            prev = self._stats_host
-            self._stats_host = {"max": np.float32(v[0]),
-                                "lower": v[1] if not np.isnan(v[1]) else prev["lower"],
-                                "median": v[2] if not np.isnan(v[2]) else prev["median"],
-                                "upper": v[3] if not np.isnan(v[3]) else prev["upper"],
-                                "length": v[4] if not np.isnan(v[4]) else prev["length"]}
+            self._stats_host = {"max": np.float32(v[0]), "lower": v[1], "median": v[2], "upper": v[3],
+                                "length": v[4]}
         return self._stats_host[key]
 
     max_ep_return = property(lambda self: self._stat("max"),

@@ -174,3 +174,35 @@ def test_cli_plumbing_config1():
     argv = "plumb env_cartpole 2 8 128 4 128 0.5 0.01 0.2 0.5 3e-4 0.99 0.95 1 1 0 0 --use_gpu 1".split()
     agent = ppo_cli.main(argv)
     assert agent.updates == 2 and agent.vec_env.num_envs == 8 and agent.last_metrics["utils/env_steps_per_sec"] > 0
+
+
+def test_episode_statistics_match_numpy_percentiles():
+    """ppo_episode_keys + sort + ppo_episode_stats vs the reference's formulas (src/ppo.py:407-417):
+    np.max / np.percentile([5, 50, 95]) over the concatenated return deques, np.percentile(50) of lengths."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    rng = np.random.default_rng(0)
+    N = 1000
+    probe = DeviceEnv("cartpole")
+    agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
+    ve = SyncVecEnv(lambda: DeviceEnv("cartpole"), N, 8, 0, 0.0, agent, seed=1)
+    assert np.isnan(ve.max_ep_return) and np.isnan(ve.median_ep_length)
+    ve._device_episode_stats()                       # no finished episode yet: stays NaN
+    assert np.isnan(ve.max_ep_return) and np.isnan(ve.lower_ep_return)
+    b = ve.batch
+    cnt = rng.integers(0, 250, N).astype(np.int32)   # some rings empty, some wrapped (> 100)
+    cnt[:10] = 0
+    ret = rng.normal(100, 40, (N, 100)).astype(np.float32)
+    ln = rng.integers(1, 500, (N, 100)).astype(np.int32)
+    b.ring_cnt.copy_(torch.from_numpy(cnt)); b.ret_ring.copy_(torch.from_numpy(ret)); b.len_ring.copy_(torch.from_numpy(ln))
+    ve._device_episode_stats()
+    valid = np.arange(100)[None, :] < np.minimum(cnt, 100)[:, None]
+    want = np.percentile(ret[valid].astype(np.float64), [5.0, 50.0, 95.0])
+    assert np.allclose([ve.lower_ep_return, ve.median_ep_return, ve.upper_ep_return], want, rtol=1e-12)
+    assert ve.max_ep_return == np.float32(ret[valid].max())
+    assert ve.median_ep_length == np.percentile(ln[valid], 50.0)
+    # running max survives a pass with smaller returns; percentiles follow the rings
+    b.ret_ring.mul_(0.5)
+    ve._device_episode_stats()
+    assert ve.max_ep_return == np.float32(ret[valid].max())
+    assert np.allclose(ve.median_ep_return, np.percentile((ret * 0.5)[valid].astype(np.float64), 50.0), rtol=1e-12)
