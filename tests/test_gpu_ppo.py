@@ -206,3 +206,52 @@ def test_episode_statistics_match_numpy_percentiles():
     ve._device_episode_stats()
     assert ve.max_ep_return == np.float32(ret[valid].max())
     assert np.allclose(ve.median_ep_return, np.percentile((ret * 0.5)[valid].astype(np.float64), 50.0), rtol=1e-12)
+
+
+class _FakeBoxEnv:
+    """Host-stepped gym.Env-protocol env with a Box action space (the shape of BASELINE configs 4-5:
+    env stepping stays on the host, only GAE and the loss run on the GPU kernels)."""
+
+    def __init__(self, seed):
+        from ppo_amd import spaces
+        from collections import deque
+        self.observation_space = spaces.Box(-np.inf, np.inf, (27,))
+        self.action_space = spaces.Box(-1.0, 1.0, (8,))
+        self.rng = np.random.default_rng(seed)
+        self.k = 0
+        self.return_queue, self.length_queue = deque(maxlen=100), deque(maxlen=100)
+        self._ret = 0.0
+
+    def reset(self):
+        self.k, self._ret = 0, 0.0
+        return self.rng.standard_normal(27).astype(np.float32), {}
+
+    def step(self, action):
+        assert np.asarray(action).shape == (8,)
+        self.k += 1
+        r = float(-np.square(action).sum())
+        self._ret += r
+        done, trunc = self.k == 17, self.k == 40
+        if done or trunc:
+            self.return_queue.append(np.float32(self._ret)); self.length_queue.append(self.k)
+        return self.rng.standard_normal(27).astype(np.float32), r, done, trunc, {}
+
+
+@pytest.mark.parametrize("use_gpu", [True, False])
+def test_host_stepped_env_uses_gpu_gae_and_loss(use_gpu):
+    """reference tests/test_vec_env.py:64-81 shapes (Ant: states (T,3,27), actions (T,3,8) f32) with a
+    stand-in env, and one full PPO update through ppo_gae_ragged / ppo_loss_fwd_bwd."""
+    from ppo_amd import PPO
+    seeds = iter(range(100))
+    ppo = PPO(0.99, 0.95, 1, 1, 0, 0, use_gpu)
+    ppo.train(lambda: _FakeBoxEnv(next(seeds)), num_updates=2, num_envs=3, steps_per_env=50, num_epochs=2,
+              batch_size=64, critic_coef=0.5, entropy_coef=0.01, clip_ratio=0.2, max_grad_norm=0.5,
+              learning_rate=3e-4, target_div=0.05)
+    ve = ppo.vec_env
+    assert not ve.native and ve.states.requires_grad
+    assert ve.states.shape == (50, 3, 27) and ve.actions.shape == (50, 3, 8) and ve.actions.dtype == torch.float32
+    assert ve.rewards.shape == (50, 3) and ve.done_flags.dtype == torch.int32 and ve.trunc_flags.dtype == torch.int32
+    assert ve.states.device.type == ("cuda" if use_gpu else "cpu")
+    ended = (ve.done_flags + ve.trunc_flags) > 0
+    assert ve.end_states.shape == (int(ended.sum()), 27) and bool(ended[-1].all())
+    assert np.isfinite(ppo.last_metrics["losses/critic_loss"]) and ve.median_ep_length == 17
