@@ -14,6 +14,7 @@ p.add_argument("--N", type=int, default=65536)
 p.add_argument("--sets", type=int, default=4)
 p.add_argument("--iters", type=int, default=40)
 p.add_argument("--variants", default="0,1,2,3,4,5")
+p.add_argument("--stagger", type=int, default=-1, help="carve the 6 arrays of a set out of one buffer, each offset by this many extra bytes (-1: separate torch allocations)")
 a = p.parse_args()
 T, N = a.T, a.N
 g = torch.Generator(device="cuda").manual_seed(1234)
@@ -25,7 +26,21 @@ for _ in range(a.sets):
     d = (torch.rand((T, N), device="cuda", generator=g) < 1 / 50).int()
     tr = ((torch.rand((T, N), device="cuda", generator=g) < 1 / 500) & (d == 0)).int()
     tr[T - 1] = 1 - d[T - 1]
-    sets.append((r, v, ev, d, tr, torch.empty_like(r)))
+    out = torch.empty_like(r)
+    if a.stagger >= 0:  # same data, placed at controlled relative offsets (HBM channel/bank interleave experiment)
+        nbytes = T * N * 4
+        pitch = nbytes + a.stagger
+        big = torch.empty(6 * pitch + 256, dtype=torch.uint8, device="cuda")
+        carved = []
+        for i, src in enumerate((r, v, ev, d, tr, out)):
+            view = big[i * pitch: i * pitch + nbytes].view(src.dtype).view(T, N)
+            view.copy_(src)
+            carved.append(view)
+        keep = big
+        r, v, ev, d, tr, out = carved
+        sets.append((r, v, ev, d, tr, out, keep))
+        continue
+    sets.append((r, v, ev, d, tr, out))
 bytes_ = 24 * T * N
 res = {}
 for variant in [int(x) for x in a.variants.split(",")]:
@@ -58,7 +73,7 @@ for i in range(a.iters + 3):
     s = sets[i % len(sets)]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    lib.ppo_stream_ceiling(*(x.data_ptr() for x in s), T * N, torch.cuda.current_stream().cuda_stream)
+    lib.ppo_stream_ceiling(*(x.data_ptr() for x in s[:6]), T * N, torch.cuda.current_stream().cuda_stream)
     e1.record()
     times.append((e0, e1))
 torch.cuda.synchronize()
