@@ -113,7 +113,7 @@ int ppo_gae_ragged(const float *rewards, const float *values, const float *end_v
                    float *adv, int T, int N, void *workspace, size_t workspace_bytes,
                    int *err_flag, void *stream);
 
-/* Bytes of device workspace ppo_adv_stats / ppo_loss_fwd_bwd need for B samples. */
+/* Bytes of device workspace ppo_adv_stats / ppo_loss_fwd_bwd / ppo_loss_logits_fwd_bwd need for B samples. */
 size_t ppo_loss_workspace_bytes(long B);
 
 /*
@@ -144,6 +144,25 @@ int ppo_loss_fwd_bwd(const float *x, const float *old_lp, const float *new_v,
                      double clip, int norm_adv, int clip_va, int ratio_input, long B,
                      float *out4, float *g_x, float *g_v, void *workspace,
                      size_t workspace_bytes, void *stream);
+
+/*
+ * The same loss for a Discrete (Categorical) policy head, taking the head's raw logits: also folds
+ * in what Agent.get_actions_and_values does with torch.distributions.Categorical on the update
+ * path (src/ppo.py:186-189 logits -> distribution, :212 log_prob(actions), :214 entropy().mean())
+ * and the ratio at :595, so log-softmax / probs / entropy tensors are never materialised.
+ *   logits  [B, num_actions] f32 row-major, 2 <= num_actions <= 8;  actions [B] i32
+ *   out5    device f32[5] = policy_loss, value_loss, clip_frac, kl_div, mean entropy
+ *   g_logits_pl  [B, num_actions]  d policy_loss / d logits   (NULL to skip)
+ *   g_logits_ent [B, num_actions]  d mean-entropy / d logits  (NULL to skip)
+ *   g_v          [B]               d value_loss / d new_v     (NULL to skip)
+ * Everything else as ppo_loss_fwd_bwd with ratio_input = 0.
+ */
+int ppo_loss_logits_fwd_bwd(const float *logits, int num_actions, const int *actions,
+                            const float *old_lp, const float *new_v, const float *old_v,
+                            const float *adv, const double *stats3, double clip, int norm_adv,
+                            int clip_va, long B, float *out5, float *g_logits_pl,
+                            float *g_logits_ent, float *g_v, void *workspace,
+                            size_t workspace_bytes, void *stream);
 
 /*
  * Categorical sampling for the rollout's policy step: for each row of logits[N,A]

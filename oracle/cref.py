@@ -107,6 +107,27 @@ def loss(x, old_lp, new_v, old_v, adv, clip, norm_adv, clip_va, ratio_input, sta
     return out4, gx, gv
 
 
+def loss_logits(logits, actions, old_lp, new_v, old_v, adv, clip, norm_adv, clip_va, stats3=None):
+    """Categorical head on raw logits (src/ppo.py:186-189,212-214) + :595 + :490-527.
+    Returns (out5, g_logits_pl, g_logits_ent, g_v)."""
+    lg = np.ascontiguousarray(logits, np.float32)
+    B, A = lg.shape
+    act = _i32(actions).ravel()
+    olp, nv, ov, a = _f32(old_lp).ravel(), _f32(new_v).ravel(), _f32(old_v).ravel(), _f32(adv).ravel()
+    if stats3 is None:
+        stats3 = adv_stats(a)
+    stats3 = np.ascontiguousarray(stats3, np.float64)
+    out5 = np.empty((5,), np.float32)
+    gpl, gent = np.empty((B, A), np.float32), np.empty((B, A), np.float32)
+    gv, s1, s2 = np.empty((B,), np.float32), np.empty((B,), np.float32), np.empty((B,), np.float32)
+    lib().oracle_loss_logits(
+        _p(lg, C.c_float), C.c_int(A), _p(act, C.c_int), _p(olp, C.c_float), _p(nv, C.c_float),
+        _p(ov, C.c_float), _p(a, C.c_float), _p(stats3, C.c_double), C.c_double(clip),
+        C.c_int(int(norm_adv)), C.c_int(int(clip_va)), C.c_long(B), _p(out5, C.c_float),
+        _p(gpl, C.c_float), _p(gent, C.c_float), _p(gv, C.c_float), _p(s1, C.c_float), _p(s2, C.c_float))
+    return out5, gpl, gent, gv
+
+
 def philox4x32_10(ctr, key):
     c = np.ascontiguousarray(ctr, np.uint32)
     k = np.ascontiguousarray(key, np.uint32)

@@ -176,6 +176,64 @@ def gen_loss(ppo_mod):
     print("loss cases:", idx)
 
 
+def gen_loss_logits(ppo_mod, spaces):
+    """Discrete head on the update path: the reference's Agent.get_actions_and_values
+    (src/ppo.py:166-216, Categorical log_prob + entropy) -> ratio (:595) -> compute_losses
+    (:490-527), with autograd gradients w.r.t. the policy head's output (the logits)."""
+    cases = {}
+    rng = np.random.default_rng(11)
+    idx = 0
+    for A in (2, 3, 6):
+        for B in (1, 5, 257, 2048):
+            for (norm_adv, clip_va) in ((0, 0), (1, 1)):
+                if B == 1 and norm_adv:
+                    continue
+                torch.manual_seed(100 + idx)
+                agent = ppo_mod.Agent(spaces.Box(-1.0, 1.0, (4,)), spaces.Discrete(A), conv_net=0, joint_net=1,
+                                      device="cpu")
+                with torch.no_grad():
+                    agent.policy.weight.mul_(150.0)  # gain-0.01 init gives near-uniform logits; spread them
+                grabbed = {}
+
+                def hook(_m, _inp, out):
+                    out.retain_grad()
+                    grabbed["logits"] = out
+
+                h = agent.policy.register_forward_hook(hook)
+                states = torch.tensor(rng.standard_normal((B, 4)).astype(np.float32))
+                actions = torch.tensor(rng.integers(0, A, B).astype(np.int32))
+                _, new_lp, new_v, ent = agent.get_actions_and_values(states, actions)
+                h.remove()
+                new_v.retain_grad()
+                logits = grabbed["logits"]
+                old_lp = (new_lp.detach().numpy() + 0.15 * rng.standard_normal(B)).astype(np.float32)
+                old_v = (new_v.detach().numpy() + 0.3 * rng.standard_normal(B)).astype(np.float32)
+                adv = rng.standard_normal(B).astype(np.float32)
+                p = ppo_mod.PPO(0.99, 0.95, norm_adv, clip_va, 0, 1, False)
+                ratio = torch.exp(new_lp - torch.tensor(old_lp))  # src/ppo.py:595
+                pl, vl, cf, kl = p.compute_losses(ratio, new_v, torch.tensor(old_v), torch.tensor(adv), 0.2)
+                pl.backward(retain_graph=True)
+                g_pl = logits.grad.clone().numpy()
+                logits.grad = None
+                ent.backward(retain_graph=True)
+                g_ent = logits.grad.clone().numpy()
+                new_v.grad = None
+                vl.backward()
+                g_v = new_v.grad.clone().numpy()
+                pre = f"c{idx}_"
+                cases.update({pre + "logits": logits.detach().numpy(), pre + "actions": actions.numpy(),
+                              pre + "old_lp": old_lp, pre + "new_v": new_v.detach().numpy(), pre + "old_v": old_v,
+                              pre + "adv": adv, pre + "cfg": np.array([norm_adv, clip_va, 0.2]),
+                              pre + "new_lp": new_lp.detach().numpy(),
+                              pre + "out5": np.array([pl.item(), vl.item(), cf.item(), kl.item(), ent.item()],
+                                                     np.float32),
+                              pre + "g_pl": g_pl, pre + "g_ent": g_ent, pre + "g_v": g_v})
+                idx += 1
+    cases["n_cases"] = np.array(idx)
+    np.savez_compressed(os.path.join(OUT, "ref_loss_logits.npz"), **cases)
+    print("loss-logits cases:", idx)
+
+
 class ScriptedEnv:
     """Deterministic fake env (gym.Env protocol, src/ppo.py:272,296): obs encodes
     (env id, episode number, step in episode); done/trunc follow a fixed schedule."""
@@ -244,3 +302,4 @@ if __name__ == "__main__":
     gen_gae(ppo_mod)
     gen_loss(ppo_mod)
     gen_rollout(ppo_mod, spaces)
+    gen_loss_logits(ppo_mod, spaces)

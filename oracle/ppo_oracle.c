@@ -209,6 +209,61 @@ void oracle_loss(const float *x, const float *old_lp, const float *new_v,
     out4[3] = (float)(s_kl / (double)B);
 }
 
+/* The same loss for a Categorical head given raw logits[B,A]: restates what
+ * Agent.get_actions_and_values does on the update path with
+ * torch.distributions.Categorical (src/ppo.py:186-189 logits -> distribution, :212
+ * log_prob(actions), :214 entropy().mean()): normalised logits = logits -
+ * logsumexp, probs = softmax, entropy = -sum p log p; then oracle_loss on the
+ * gathered log-probs, and the chain rule back to the logits:
+ *   d new_lp / d logit_k = [k == a] - p_k ;  d H / d logit_k = -p_k (log p_k + H).
+ *   out5 = policy_loss, value_loss, clip_frac, kl_div, mean entropy                */
+void oracle_loss_logits(const float *logits, int A, const int *actions, const float *old_lp,
+                        const float *new_v, const float *old_v, const float *adv,
+                        const double *stats3, double clip, int norm_adv, int clip_va, long B,
+                        float *out5, float *g_logits_pl, float *g_logits_ent, float *g_v,
+                        float *scratch_lp /* [B] */, float *scratch_glp /* [B] */)
+{
+    double s_h = 0.0;
+    const float invB = 1.0f / (float)B;
+    for (long i = 0; i < B; ++i) {
+        const float *lg = logits + i * A;
+        float mx = lg[0];
+        for (int k = 1; k < A; ++k) mx = lg[k] > mx ? lg[k] : mx;
+        float s = 0.0f;
+        for (int k = 0; k < A; ++k) s += expf(lg[k] - mx);
+        float lse = mx + logf(s);
+        float H = 0.0f;
+        for (int k = 0; k < A; ++k) {
+            float lp = lg[k] - lse, p = expf(lg[k] - mx) / s;
+            H -= lp * p;
+        }
+        scratch_lp[i] = lg[actions[i]] - lse;
+        s_h += (double)H;
+        if (g_logits_ent) {
+            for (int k = 0; k < A; ++k) {
+                float lp = lg[k] - lse, p = expf(lg[k] - mx) / s;
+                g_logits_ent[i * A + k] = -p * (lp + H) * invB;
+            }
+        }
+    }
+    oracle_loss(scratch_lp, old_lp, new_v, old_v, adv, stats3, clip, norm_adv, clip_va, 0, B, out5,
+                scratch_glp, g_v);
+    out5[4] = (float)(s_h / (double)B);
+    if (g_logits_pl) {
+        for (long i = 0; i < B; ++i) {
+            const float *lg = logits + i * A;
+            float mx = lg[0];
+            for (int k = 1; k < A; ++k) mx = lg[k] > mx ? lg[k] : mx;
+            float s = 0.0f;
+            for (int k = 0; k < A; ++k) s += expf(lg[k] - mx);
+            for (int k = 0; k < A; ++k) {
+                float p = expf(lg[k] - mx) / s;
+                g_logits_pl[i * A + k] = scratch_glp[i] * ((k == actions[i] ? 1.0f : 0.0f) - p);
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* Philox4x32-10 (Salmon et al., SC'11; Random123).  Integer arithmetic only.   */
 #define PHILOX_M0 0xD2511F53u

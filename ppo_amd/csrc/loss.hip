@@ -125,16 +125,76 @@ struct LossArgs {
     bool vec;
 };
 
+// Per-sample terms shared by both front ends (ratio / log-prob input, and logits input).
+struct LossConsts {
+    float lo, hi, epsf, mean_f, denom_f, invB;
+    int norm_adv, clip_va;
+};
+
+struct SampleOut {
+    float m, vterm, clipped, kl;  // min(w, c), value term, |rho-1| > eps, (rho-1) - log rho
+    float g_rho, g_v;             // d policy_loss / d rho, d value_loss / d new_v (both already / B)
+};
+
+__device__ __forceinline__ LossConsts loss_consts(const double *stats3, int norm_adv, int clip_va, float lo,
+                                                  float hi, float epsf, long B)
+{
+    LossConsts c;
+    c.lo = lo; c.hi = hi; c.epsf = epsf; c.norm_adv = norm_adv; c.clip_va = clip_va;
+    c.mean_f = 0.0f; c.denom_f = 1.0f;
+    if (norm_adv) {
+        const double n = stats3[0];
+        c.mean_f = (float)stats3[1];
+        const float std_f = (float)sqrt(stats3[2] / (n - 1.0));  // unbiased (torch.std), NaN at B=1
+        c.denom_f = std_f + 1e-8f;                               // src/ppo.py:501
+    }
+    c.invB = 1.0f / (float)B;
+    return c;
+}
+
+__device__ __forceinline__ SampleOut loss_sample(const LossConsts &c, float rho, float adv, float ov, float v)
+{
+    SampleOut o;
+    const float ret = adv + ov;                                       // :498
+    if (c.norm_adv) adv = (adv - c.mean_f) / c.denom_f;               // :501
+    const float rc = rho < c.lo ? c.lo : (rho > c.hi ? c.hi : rho);   // :503
+    const float w = rho * adv, cl = rc * adv;                         // :504-505
+    o.m = w < cl ? w : cl;                                            // :508
+    const bool inside = (rho >= c.lo) && (rho <= c.hi);
+    float gr;
+    if (w < cl) gr = adv;
+    else if (w > cl) gr = inside ? adv : 0.0f;
+    else gr = 0.5f * adv + (inside ? 0.5f * adv : 0.0f);              // torch.minimum tie
+    o.g_rho = -gr * c.invB;
+
+    const float e = ret - v;
+    const float se = e * e;                                           // :513 / :518
+    float gvk;
+    if (c.clip_va) {
+        const float vlo = ov - c.epsf, vhi = ov + c.epsf;             // :514
+        const float vc = v < vlo ? vlo : (v > vhi ? vhi : v);
+        const bool vin = (v >= vlo) && (v <= vhi);
+        const float ec = ret - vc;
+        const float ce = ec * ec;                                     // :515
+        o.vterm = se > ce ? se : ce;                                  // :516
+        const float g_se = -2.0f * e, g_ce = vin ? -2.0f * ec : 0.0f;
+        if (se > ce) gvk = g_se;
+        else if (se < ce) gvk = g_ce;
+        else gvk = 0.5f * g_se + 0.5f * g_ce;                         // torch.maximum tie
+    } else {
+        o.vterm = se;
+        gvk = -2.0f * e;
+    }
+    o.g_v = 0.5f * gvk * c.invB;
+    const float rm1 = rho - 1.0f;
+    o.clipped = (fabsf(rm1) > c.epsf) ? 1.0f : 0.0f;                  // :522
+    o.kl = rm1 - logf(rho);                                           // :525
+    return o;
+}
+
 __global__ void __launch_bounds__(LOSS_BLOCK) k_loss_partial(LossArgs a)
 {
-    float mean_f = 0.0f, denom_f = 1.0f;
-    if (a.norm_adv) {
-        const double n = a.stats3[0];
-        mean_f = (float)a.stats3[1];
-        const float std_f = (float)sqrt(a.stats3[2] / (n - 1.0));  // unbiased (torch.std), NaN at B=1
-        denom_f = std_f + 1e-8f;                                   // src/ppo.py:501
-    }
-    const float invB = 1.0f / (float)a.B;
+    const LossConsts c = loss_consts(a.stats3, a.norm_adv, a.clip_va, a.lo, a.hi, a.epsf, a.B);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const long G = loss_groups(a.B);
     for (long g = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x; g < G; g += (long)gridDim.x * LOSS_BLOCK) {
@@ -151,55 +211,102 @@ __global__ void __launch_bounds__(LOSS_BLOCK) k_loss_partial(LossArgs a)
         float gx[4], gv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool live = i + k < a.B;
             const float rho = a.ratio_input ? xs[k] : expf(xs[k] - ols[k]);  // :595
-            float adv = ads[k];
-            const float ret = adv + ovs[k];                                   // :498
-            if (a.norm_adv) adv = (adv - mean_f) / denom_f;                   // :501
-            const float rc = rho < a.lo ? a.lo : (rho > a.hi ? a.hi : rho);   // :503
-            const float w = rho * adv, c = rc * adv;                          // :504-505
-            const float m = w < c ? w : c;                                    // :508
-            const bool inside = (rho >= a.lo) && (rho <= a.hi);
-            float gr;
-            if (w < c) gr = adv;
-            else if (w > c) gr = inside ? adv : 0.0f;
-            else gr = 0.5f * adv + (inside ? 0.5f * adv : 0.0f);              // torch.minimum tie
-            gr = -gr * invB;
-            gx[k] = a.ratio_input ? gr : gr * rho;
-
-            const float v = nvs[k];
-            const float e = ret - v;
-            const float se = e * e;                                           // :513 / :518
-            float vterm, gvk;
-            if (a.clip_va) {
-                const float vlo = ovs[k] - a.epsf, vhi = ovs[k] + a.epsf;     // :514
-                const float vc = v < vlo ? vlo : (v > vhi ? vhi : v);
-                const bool vin = (v >= vlo) && (v <= vhi);
-                const float ec = ret - vc;
-                const float ce = ec * ec;                                     // :515
-                vterm = se > ce ? se : ce;                                    // :516
-                const float g_se = -2.0f * e, g_ce = vin ? -2.0f * ec : 0.0f;
-                if (se > ce) gvk = g_se;
-                else if (se < ce) gvk = g_ce;
-                else gvk = 0.5f * g_se + 0.5f * g_ce;                         // torch.maximum tie
-            } else {
-                vterm = se;
-                gvk = -2.0f * e;
-            }
-            gv[k] = 0.5f * gvk * invB;
-
-            const float rm1 = rho - 1.0f;
-            if (live) {
-                acc[0] += (double)m;
-                acc[1] += (double)vterm;
-                acc[2] += (fabsf(rm1) > a.epsf) ? 1.0 : 0.0;                  // :522
-                acc[3] += (double)(rm1 - logf(rho));                          // :525
+            const SampleOut o = loss_sample(c, rho, ads[k], ovs[k], nvs[k]);
+            gx[k] = a.ratio_input ? o.g_rho : o.g_rho * rho;
+            gv[k] = o.g_v;
+            if (i + k < a.B) {
+                acc[0] += (double)o.m;
+                acc[1] += (double)o.vterm;
+                acc[2] += (double)o.clipped;
+                acc[3] += (double)o.kl;
             }
         }
         if (a.g_x) st4(a.g_x, i, a.B, a.vec, make_float4(gx[0], gx[1], gx[2], gx[3]));
         if (a.g_v) st4(a.g_v, i, a.B, a.vec, make_float4(gv[0], gv[1], gv[2], gv[3]));
     }
     block_reduce_store<4>(acc, a.partials + (size_t)blockIdx.x * 4);
+}
+
+// ---- discrete-policy front end: logits in, entropy and both logits gradients out ----------
+// Folds what the reference does with torch.distributions.Categorical in get_actions_and_values
+// (src/ppo.py:201-216: logits - logsumexp, log_prob gather, entropy = -sum p log p, .mean()) into
+// the loss pass, so the update never materialises log-softmax / probs / entropy tensors.
+struct LossLogitsArgs {
+    const float *logits;   // [B, A] row-major
+    const int *actions;    // [B]
+    const float *old_lp, *new_v, *old_v, *adv;
+    const double *stats3;
+    float *g_logits_pl, *g_logits_ent, *g_v;  // [B, A], [B, A], [B]; any may be NULL
+    double *partials;
+    float lo, hi, epsf;
+    long B;
+    int norm_adv, clip_va;
+};
+
+template <int A> __global__ void __launch_bounds__(LOSS_BLOCK) k_loss_logits_partial(LossLogitsArgs a)
+{
+    const LossConsts c = loss_consts(a.stats3, a.norm_adv, a.clip_va, a.lo, a.hi, a.epsf, a.B);
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (long i = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < a.B; i += (long)gridDim.x * LOSS_BLOCK) {
+        float lg[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) lg[k] = a.logits[i * A + k];
+        float mx = lg[0];
+#pragma unroll
+        for (int k = 1; k < A; ++k) mx = fmaxf(mx, lg[k]);
+        float ex[A], s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) { ex[k] = expf(lg[k] - mx); s += ex[k]; }
+        const float lse = mx + logf(s);                 // torch.logsumexp
+        const int act = a.actions[i];
+        float lp[A], pr[A], H = 0.0f, new_lp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            lp[k] = lg[k] - lse;                        // Categorical.logits (normalised)
+            pr[k] = ex[k] / s;                          // Categorical.probs (softmax)
+            H -= lp[k] * pr[k];                         // Categorical.entropy
+            if (k == act) new_lp = lp[k];               // Categorical.log_prob
+        }
+        const float rho = expf(new_lp - a.old_lp[i]);   // :595
+        const SampleOut o = loss_sample(c, rho, a.adv[i], a.old_v[i], a.new_v[i]);
+        const float g_lp = o.g_rho * rho;               // d policy_loss / d new_lp
+        if (a.g_logits_pl) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) a.g_logits_pl[i * A + k] = g_lp * ((k == act ? 1.0f : 0.0f) - pr[k]);
+        }
+        if (a.g_logits_ent) {                           // d mean(H) / d logits_k = -p_k (log p_k + H) / B
+#pragma unroll
+            for (int k = 0; k < A; ++k) a.g_logits_ent[i * A + k] = -pr[k] * (lp[k] + H) * c.invB;
+        }
+        if (a.g_v) a.g_v[i] = o.g_v;
+        acc[0] += (double)o.m;
+        acc[1] += (double)o.vterm;
+        acc[2] += (double)o.clipped;
+        acc[3] += (double)o.kl;
+        acc[4] += (double)H;
+    }
+    block_reduce_store<5>(acc, a.partials + (size_t)blockIdx.x * 5);
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_loss_logits_final(const double *partials, int nblocks, long B,
+                                                                float *out5)
+{
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += LOSS_BLOCK) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += partials[(size_t)b * 5 + k];
+    }
+    __shared__ double tot[5];
+    block_reduce_store<5>(acc, tot);
+    if (threadIdx.x == 0) {
+        const double n = (double)B;
+        out5[0] = (float)(-tot[0] / n);
+        out5[1] = (float)(0.5 * tot[1] / n);
+        out5[2] = (float)(tot[2] / n);
+        out5[3] = (float)(tot[3] / n);
+        out5[4] = (float)(tot[4] / n);
+    }
 }
 
 __global__ void __launch_bounds__(LOSS_BLOCK) k_loss_final(const double *partials, int nblocks, long B, float *out4)
@@ -227,7 +334,7 @@ extern "C" {
 size_t ppo_loss_workspace_bytes(long B)
 {
     (void)B;
-    return (size_t)LOSS_MAX_BLOCKS * 4 * sizeof(double);
+    return (size_t)LOSS_MAX_BLOCKS * 5 * sizeof(double);
 }
 
 int ppo_adv_stats(const float *adv, long B, double *stats3, void *workspace, size_t workspace_bytes,
@@ -270,6 +377,35 @@ int ppo_loss_fwd_bwd(const float *x, const float *old_lp, const float *new_v, co
     int rc = ppo_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(LOSS_BLOCK), 0, s, a.partials, grid, B, out4);
+    return ppo_launch_status();
+}
+
+int ppo_loss_logits_fwd_bwd(const float *logits, int num_actions, const int *actions, const float *old_lp,
+                            const float *new_v, const float *old_v, const float *adv, const double *stats3,
+                            double clip, int norm_adv, int clip_va, long B, float *out5, float *g_logits_pl,
+                            float *g_logits_ent, float *g_v, void *workspace, size_t workspace_bytes, void *stream)
+{
+    PPO_REQUIRE(logits && actions && old_lp && new_v && old_v && adv && out5 && B >= 1);
+    PPO_REQUIRE(num_actions >= 2 && num_actions <= 8);
+    PPO_REQUIRE(!norm_adv || stats3);
+    PPO_REQUIRE(workspace && workspace_bytes >= ppo_loss_workspace_bytes(B) && ppo_aligned(workspace, 8));
+    hipStream_t s = (hipStream_t)stream;
+    LossLogitsArgs a;
+    a.logits = logits; a.actions = actions; a.old_lp = old_lp; a.new_v = new_v; a.old_v = old_v; a.adv = adv;
+    a.stats3 = stats3; a.g_logits_pl = g_logits_pl; a.g_logits_ent = g_logits_ent; a.g_v = g_v;
+    a.partials = reinterpret_cast<double *>(workspace);
+    a.lo = (float)(1.0 - clip); a.hi = (float)(1.0 + clip); a.epsf = (float)clip;
+    a.B = B; a.norm_adv = norm_adv; a.clip_va = clip_va;
+    long blocks = (B + LOSS_BLOCK - 1) / LOSS_BLOCK;
+    const int grid = (int)(blocks > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : blocks);
+    switch (num_actions) {
+#define PPO_CASE(A_) case A_: hipLaunchKernelGGL(k_loss_logits_partial<A_>, dim3(grid), dim3(LOSS_BLOCK), 0, s, a); break;
+        PPO_CASE(2) PPO_CASE(3) PPO_CASE(4) PPO_CASE(5) PPO_CASE(6) PPO_CASE(7) PPO_CASE(8)
+#undef PPO_CASE
+    }
+    int rc = ppo_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_loss_logits_final, dim3(1), dim3(LOSS_BLOCK), 0, s, a.partials, grid, B, out5);
     return ppo_launch_status();
 }
 

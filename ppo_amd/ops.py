@@ -169,6 +169,50 @@ def ppo_losses(x, new_v, old_lp, old_v, adv, clip, norm_adv, clip_va, ratio_inpu
     return pl, vl, cf, kl
 
 
+def loss_logits_fwd_bwd(logits, actions, old_lp, new_v, old_v, adv, clip, norm_adv, clip_va, stats3=None,
+                        want_grads=True):
+    """ppo_loss_logits_fwd_bwd: returns (out5 [device f32x5], g_logits_pl, g_logits_ent, g_v)."""
+    lib = _lib.load()
+    lg = _dev(logits, torch.float32)
+    assert lg.dim() == 2, "logits must be [B, num_actions]"
+    B, A = lg.shape
+    act = _dev(actions, torch.int32).reshape(-1)
+    olp, nv, ov, a = (_dev(t, torch.float32).reshape(-1) for t in (old_lp, new_v, old_v, adv))
+    assert act.numel() == B and olp.numel() == B and nv.numel() == B and ov.numel() == B and a.numel() == B
+    if norm_adv and stats3 is None:
+        stats3 = adv_stats(a)
+    dev = lg.device
+    out5 = torch.empty(5, dtype=torch.float32, device=dev)
+    g_pl = torch.empty(B, A, dtype=torch.float32, device=dev) if want_grads else None
+    g_ent = torch.empty(B, A, dtype=torch.float32, device=dev) if want_grads else None
+    g_v = torch.empty(B, dtype=torch.float32, device=dev) if want_grads else None
+    ws = _workspace(lib.ppo_loss_workspace_bytes(B), dev)
+    rc = lib.ppo_loss_logits_fwd_bwd(_ptr(lg), A, _ptr(act), _ptr(olp), _ptr(nv), _ptr(ov), _ptr(a), _ptr(stats3),
+                                     float(clip), int(bool(norm_adv)), int(bool(clip_va)), B, _ptr(out5),
+                                     _ptr(g_pl), _ptr(g_ent), _ptr(g_v), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "ppo_loss_logits_fwd_bwd")
+    return out5, g_pl, g_ent, g_v
+
+
+def ppo_losses_discrete(logits, actions, new_v, old_lp, old_v, adv, clip, norm_adv, clip_va, stats3=None):
+    """(policy_loss, value_loss, clip_frac, kl_div, entropy) for a Categorical head given its raw
+    logits; policy_loss and entropy are differentiable w.r.t. logits, value_loss w.r.t. new_v.
+    One kernel pass replaces Categorical(logits).log_prob / .entropy().mean() (reference
+    src/ppo.py:186-189,212-214), the ratio (:595) and compute_losses (:490-527)."""
+    need = torch.is_grad_enabled() and (logits.requires_grad or new_v.requires_grad)
+    with torch.no_grad():
+        out5, g_pl, g_ent, g_v = loss_logits_fwd_bwd(logits, actions, old_lp, new_v, old_v, adv, float(clip),
+                                                     bool(norm_adv), bool(clip_va), stats3=stats3, want_grads=need)
+        o = out5.to(logits.device)
+    pl, vl, cf, kl, ent = o[0], o[1], o[2], o[3], o[4]
+    if need and logits.requires_grad:
+        pl = _AttachGrad.apply(logits, pl, g_pl)
+        ent = _AttachGrad.apply(logits, ent, g_ent)
+    if need and new_v.requires_grad:
+        vl = _AttachGrad.apply(new_v, vl, g_v)
+    return pl, vl, cf, kl, ent
+
+
 # --------------------------------------------------------------------------- sampling
 def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int, action_out=None, logp_out=None):
     lib = _lib.load()

@@ -486,6 +486,9 @@ class PPO:
         self.device = "cuda" if (use_gpu and torch.cuda.is_available()) else "cpu"
         self.updates = 0
         self.last_metrics: dict = {}
+        # Discrete heads: log-prob, entropy, ratio and losses in one kernel (ppo_loss_logits_fwd_bwd);
+        # False keeps torch.distributions.Categorical in front of ppo_loss_fwd_bwd.
+        self.fused_discrete_loss = True
 
     # -- hot path: GAE --------------------------------------------------------------------
     def compute_advantages(self, rewards, values, end_values, done_flags, trunc_flags):
@@ -530,19 +533,27 @@ class PPO:
         clip_sum = torch.zeros((), dtype=torch.float32, device=dev)
         grad_steps_done = 0
         params = [p for p in self.agent.parameters()]
+        fused_head = (self.fused_discrete_loss and self.agent.discrete and self.agent.action_space.n <= 8
+                      and actions.dtype == torch.int32)
         for _epoch in range(num_epochs):
             perm = torch.randperm(data_size, device=dev)       # reference :575-576 (np.random.shuffle)
             for start in range(0, data_size, batch_size):
                 idx = perm[start:start + batch_size]           # last minibatch may be short (:581)
                 mb_states, mb_actions = states[idx], actions[idx]
                 mb_log_probs, mb_values, mb_adv = log_probs[idx], values[idx], advantages[idx]
-                _, new_log_probs, new_values, entropy = self.agent.get_actions_and_values(mb_states, mb_actions)
                 stats3 = None
                 if self.norm_adv and world > 1:                # keep minibatch normalisation global
                     stats3 = ppo_dist.merged_adv_stats(ops.adv_stats(mb_adv))
-                policy_loss, critic_loss, clip_frac, kl_div = ops.ppo_losses(
-                    new_log_probs, new_values, mb_log_probs, mb_values, mb_adv, clip_ratio,
-                    self.norm_adv, self.clip_va_loss, ratio_input=False, stats3=stats3)  # :595-599
+                if fused_head:   # Categorical log-prob + entropy + ratio + losses in one pass (:186-216, :595-599)
+                    logits, new_values = self.agent.policy_and_values(mb_states)
+                    policy_loss, critic_loss, clip_frac, kl_div, entropy = ops.ppo_losses_discrete(
+                        logits, mb_actions, new_values, mb_log_probs, mb_values, mb_adv, clip_ratio,
+                        self.norm_adv, self.clip_va_loss, stats3=stats3)
+                else:
+                    _, new_log_probs, new_values, entropy = self.agent.get_actions_and_values(mb_states, mb_actions)
+                    policy_loss, critic_loss, clip_frac, kl_div = ops.ppo_losses(
+                        new_log_probs, new_values, mb_log_probs, mb_values, mb_adv, clip_ratio,
+                        self.norm_adv, self.clip_va_loss, ratio_input=False, stats3=stats3)  # :595-599
                 if self.joint_network:                         # reference :602-609
                     total = (policy_loss + critic_coef * critic_loss - entropy_coef * entropy) * lr_anneal
                     self.pi_optimizer.zero_grad()

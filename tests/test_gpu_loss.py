@@ -160,3 +160,88 @@ def test_deterministic_and_linear_in_B():
     c = ops.loss_fwd_bwd(*twice, 0.2, 1, 1, 0, stats3=stats2)
     assert torch.allclose(c[0], a[0], rtol=RTOL, atol=1e-8)
     assert torch.allclose(c[1][:B] * 2, a[1], rtol=RTOL, atol=1e-12)
+
+
+# ---- discrete-head front end: ppo_loss_logits_fwd_bwd ------------------------------------------
+def _check_logits(out5, gpl, gent, gv, ref5, rpl, rent, rv, tag):
+    out5 = out5.cpu().numpy()
+    assert np.allclose(out5[:3], ref5[:3], rtol=2 * RTOL, atol=1e-7), tag
+    assert abs(out5[3] - ref5[3]) <= RTOL * abs(ref5[3]) + 2e-7, tag
+    assert abs(out5[4] - ref5[4]) <= RTOL * abs(ref5[4]) + 1e-7, tag
+    for got, want, key in ((gpl, rpl, "g_pl"), (gent, rent, "g_ent"), (gv, rv, "g_v")):
+        got = got.cpu().numpy()
+        # softmax / log-softmax cancel in f32: 2e-5 relative to the largest gradient entry
+        assert np.abs(got - want).max() <= 2 * RTOL * max(np.abs(want).max(), 1e-30) + 1e-9, f"{tag} {key}"
+
+
+def test_logits_golden_values_and_gradients(golden_dir):
+    """vs the reference's Agent.get_actions_and_values (Categorical) + compute_losses + autograd."""
+    from ppo_amd import ops
+    L = np.load(os.path.join(golden_dir, "ref_loss_logits.npz"))
+    for i in range(int(L["n_cases"])):
+        p = f"c{i}_"
+        norm_adv, clip_va, clip = L[p + "cfg"]
+        t = {k: torch.from_numpy(L[p + k]).cuda() for k in ("logits", "actions", "old_lp", "new_v", "old_v", "adv")}
+        out5, gpl, gent, gv = ops.loss_logits_fwd_bwd(t["logits"], t["actions"], t["old_lp"], t["new_v"], t["old_v"],
+                                                      t["adv"], float(clip), int(norm_adv), int(clip_va))
+        _check_logits(out5, gpl, gent, gv, L[p + "out5"], L[p + "g_pl"], L[p + "g_ent"], L[p + "g_v"], f"case {i}")
+
+
+@pytest.mark.parametrize("A", [2, 3, 5, 8])
+@pytest.mark.parametrize("B", [1, 63, 4097, 1 << 20])
+def test_logits_vs_oracle_sizes(A, B):
+    from ppo_amd import ops
+    rng = np.random.default_rng(A * 1000 + B)
+    logits = (2.0 * rng.standard_normal((B, A))).astype(np.float32)
+    actions = rng.integers(0, A, B).astype(np.int32)
+    old_lp = -np.abs(rng.standard_normal(B)).astype(np.float32)
+    old_v = rng.standard_normal(B).astype(np.float32)
+    new_v = (old_v + 0.3 * rng.standard_normal(B)).astype(np.float32)
+    adv = (1.0 + 2.0 * rng.standard_normal(B)).astype(np.float32)
+    norm_adv = int(B > 1)
+    w5, wpl, went, wv = cref.loss_logits(logits, actions, old_lp, new_v, old_v, adv, 0.2, norm_adv, 1)
+    t = [torch.from_numpy(x).cuda() for x in (logits, actions, old_lp, new_v, old_v, adv)]
+    out5, gpl, gent, gv = ops.loss_logits_fwd_bwd(*t, 0.2, norm_adv, 1)
+    _check_logits(out5, gpl, gent, gv, w5, wpl, went, wv, f"A={A} B={B}")
+
+
+def test_logits_front_end_equals_two_stage_path_and_autograd():
+    """ops.ppo_losses_discrete == Categorical(log_prob, entropy) + ops.ppo_losses, values and the
+    gradients that reach the network parameters (joint net, the way train_step combines them)."""
+    from ppo_amd import Agent, ops, spaces
+    torch.manual_seed(3)
+    agent = Agent(spaces.Box(-1.0, 1.0, (6,)), spaces.Discrete(3), conv_net=0, joint_net=1, device="cuda")
+    with torch.no_grad():
+        agent.policy.weight.mul_(100.0)
+    B = 5000
+    states = torch.randn(B, 6, device="cuda")
+    actions = torch.randint(0, 3, (B,), device="cuda", dtype=torch.int32)
+    old_lp = -torch.rand(B, device="cuda")
+    old_v = torch.randn(B, device="cuda")
+    adv = torch.randn(B, device="cuda")
+
+    def grads(fused):
+        agent.zero_grad()
+        if fused:
+            logits, v = agent.policy_and_values(states)
+            pl, vl, cf, kl, ent = ops.ppo_losses_discrete(logits, actions, v, old_lp, old_v, adv, 0.2, 1, 1)
+        else:
+            _, lp, v, ent = agent.get_actions_and_values(states, actions)
+            pl, vl, cf, kl = ops.ppo_losses(lp, v, old_lp, old_v, adv, 0.2, 1, 1, ratio_input=False)
+        (pl + 0.5 * vl - 0.01 * ent).backward()
+        return [x.item() for x in (pl, vl, cf, kl, ent)], [p.grad.clone() for p in agent.parameters()]
+
+    (s1, g1), (s2, g2) = grads(True), grads(False)
+    for a, b in zip(s1, s2):
+        assert abs(a - b) <= 2 * RTOL * abs(b) + 2e-7
+    for a, b in zip(g1, g2):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9
+
+
+def test_logits_rejects_bad_arguments():
+    from ppo_amd import ops, _lib
+    B = 8
+    z = torch.zeros(B, device="cuda")
+    with pytest.raises(_lib.PpoAmdError):   # 9 actions: outside the compiled 2..8 range
+        ops.loss_logits_fwd_bwd(torch.zeros(B, 9, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda"),
+                                z, z, z, z, 0.2, 0, 0)

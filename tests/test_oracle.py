@@ -131,6 +131,24 @@ def test_oracle_loss_golden(golden_dir):
 
 
 # -- Philox ---------------------------------------------------------------------------------------
+def test_oracle_loss_logits_golden(golden_dir):
+    """Discrete head restatement (Categorical log_prob / entropy + loss) vs the reference's
+    Agent.get_actions_and_values + compute_losses outputs and autograd gradients."""
+    L = np.load(os.path.join(golden_dir, "ref_loss_logits.npz"))
+    for i in range(int(L["n_cases"])):
+        p = f"c{i}_"
+        norm_adv, clip_va, clip = L[p + "cfg"]
+        out5, gpl, gent, gv = cref.loss_logits(L[p + "logits"], L[p + "actions"], L[p + "old_lp"], L[p + "new_v"],
+                                               L[p + "old_v"], L[p + "adv"], float(clip), int(norm_adv), int(clip_va))
+        ref = L[p + "out5"]
+        assert np.allclose(out5[:3], ref[:3], rtol=2e-5, atol=1e-7), f"case {i}"
+        assert abs(out5[3] - ref[3]) <= 1e-5 * abs(ref[3]) + 2e-7, f"case {i}"
+        assert abs(out5[4] - ref[4]) <= 1e-5 * abs(ref[4]) + 1e-7, f"case {i}"
+        for got, key in ((gpl, "g_pl"), (gent, "g_ent"), (gv, "g_v")):
+            want = L[p + key]
+            assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-30) + 1e-9, f"case {i} {key}"
+
+
 def test_philox_known_answers():
     """Random123 kat_vectors, philox4x32 10 rounds"""
     kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
