@@ -165,6 +165,23 @@ int ppo_loss_logits_fwd_bwd(const float *logits, int num_actions, const int *act
                             size_t workspace_bytes, void *stream);
 
 /*
+ * One-launch minibatch gather for the update phase: out[i] = in[idx[i]] for the observations,
+ * actions, old log-probs, old values and advantages of the flattened rollout (M = T*N rows).
+ * Replaces the five fancy-index gathers at src/ppo.py:582-588 (the shuffled index list of
+ * :575-576 stays a device permutation made by the caller).
+ *   idx [B] i64 (negative values wrap like torch/numpy); rows of states / actions are
+ *   state_words / action_words 32-bit words wide (f32 observations; i32 Discrete or f32 Box
+ *   actions).  Any of the five sources may be NULL to skip it.
+ *   err_flag (i32, may be NULL) is set to 1 and the row zero-filled where torch would raise
+ *   IndexError (index outside [-M, M)).
+ */
+int ppo_minibatch_gather(const int64_t *idx, long B, long M, const void *states, int state_words,
+                         const void *actions, int action_words, const float *log_probs,
+                         const float *values, const float *adv, void *mb_states, void *mb_actions,
+                         float *mb_log_probs, float *mb_values, float *mb_adv, int *err_flag,
+                         void *stream);
+
+/*
  * Categorical sampling for the rollout's policy step: for each row of logits[N,A]
  * draw an action with Philox4x32-10 keyed (seed; env_base+n, step) and return its
  * log-probability.  Replaces torch.distributions.Categorical(logits).sample() and

@@ -213,6 +213,33 @@ def ppo_losses_discrete(logits, actions, new_v, old_lp, old_v, adv, clip, norm_a
     return pl, vl, cf, kl, ent
 
 
+# --------------------------------------------------------------------------- minibatch
+def minibatch_gather(idx, states, actions, log_probs, values, adv, check_index=False):
+    """(states[idx], actions[idx], log_probs[idx], values[idx], adv[idx]) in one launch
+    (reference src/ppo.py:582-588).  All inputs are flattened-rollout tensors with M rows."""
+    lib = _lib.load()
+    dev = device()
+    ix = idx.to(dev, torch.int64).contiguous()
+    st, lp, v, a = (_dev(t, torch.float32) for t in (states, log_probs, values, adv))
+    act = actions.to(dev).contiguous()
+    assert act.dtype in (torch.int32, torch.float32), "actions must be i32 (Discrete) or f32 (Box)"
+    M, B = st.shape[0], ix.numel()
+    assert act.shape[0] == M and lp.numel() == M and v.numel() == M and a.numel() == M
+    sw = st[0].numel() if M else 0
+    aw = act[0].numel() if M else 0
+    mb_st = torch.empty((B, *st.shape[1:]), dtype=torch.float32, device=dev)
+    mb_act = torch.empty((B, *act.shape[1:]), dtype=act.dtype, device=dev)
+    mb_lp, mb_v, mb_a = (torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3))
+    err = torch.zeros(1, dtype=torch.int32, device=dev) if check_index else None
+    rc = lib.ppo_minibatch_gather(_ptr(ix), B, M, _ptr(st), sw, _ptr(act), aw, _ptr(lp), _ptr(v), _ptr(a),
+                                  _ptr(mb_st), _ptr(mb_act), _ptr(mb_lp), _ptr(mb_v), _ptr(mb_a), _ptr(err),
+                                  _stream())
+    _lib.check(rc, "ppo_minibatch_gather")
+    if check_index and int(err.item()):
+        raise IndexError("minibatch index out of range")
+    return mb_st, mb_act, mb_lp, mb_v, mb_a
+
+
 # --------------------------------------------------------------------------- sampling
 def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int, action_out=None, logp_out=None):
     lib = _lib.load()

@@ -535,12 +535,18 @@ class PPO:
         params = [p for p in self.agent.parameters()]
         fused_head = (self.fused_discrete_loss and self.agent.discrete and self.agent.action_space.n <= 8
                       and actions.dtype == torch.int32)
+        fused_gather = (dev.type == "cuda" and actions.dtype in (torch.int32, torch.float32)
+                        and states.dtype == torch.float32)
         for _epoch in range(num_epochs):
             perm = torch.randperm(data_size, device=dev)       # reference :575-576 (np.random.shuffle)
             for start in range(0, data_size, batch_size):
                 idx = perm[start:start + batch_size]           # last minibatch may be short (:581)
-                mb_states, mb_actions = states[idx], actions[idx]
-                mb_log_probs, mb_values, mb_adv = log_probs[idx], values[idx], advantages[idx]
+                if fused_gather:                               # one launch for the five gathers (:582-588)
+                    mb_states, mb_actions, mb_log_probs, mb_values, mb_adv = ops.minibatch_gather(
+                        idx, states, actions, log_probs, values, advantages)
+                else:
+                    mb_states, mb_actions = states[idx], actions[idx]
+                    mb_log_probs, mb_values, mb_adv = log_probs[idx], values[idx], advantages[idx]
                 stats3 = None
                 if self.norm_adv and world > 1:                # keep minibatch normalisation global
                     stats3 = ppo_dist.merged_adv_stats(ops.adv_stats(mb_adv))
