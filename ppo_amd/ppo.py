@@ -151,6 +151,9 @@ class Agent(nn.Module):
         return actions, dist.log_prob(actions), values, dist.entropy().mean()
 
 
+_BATCH_TENSORS = ("state", "elapsed", "ep_ret", "ep_len", "episode", "ret_ring", "len_ring", "ring_cnt")
+
+
 # ----------------------------------------------------------------------------------------
 class SyncVecEnv:
     """Vectorised env + rollout collector with the reference's contract (src/ppo.py:218-417).
@@ -403,6 +406,46 @@ class SyncVecEnv:
     median_ep_length = property(lambda self: self._stat("length"),
                                 lambda self, v: self._stats_host.__setitem__("length", v))
 
+    # -- checkpoint (no counterpart in the reference, which keeps no state_dict) -------
+    def state_dict(self) -> dict:
+        """Everything a resumed run needs to continue the env batch bit for bit: physics state,
+        TimeLimit / episode counters (the Philox reset position), statistics rings, the carried
+        observations and the rollout counter (the Philox sampling position)."""
+        if not self.native:
+            raise NotImplementedError("host-stepped gym envs are opaque objects; only device-resident env "
+                                      "batches can be checkpointed")
+        b = self.batch
+        torch.cuda.synchronize()
+        _ = self.max_ep_return                       # drain the statistics stream into _stats_host
+        sd = {name: getattr(b, name).cpu() for name in _BATCH_TENSORS}
+        sd.update({"kind": b.kind, "num_envs": b.num_envs, "seed": b.seed, "env_base": b.env_base, "ring": b.ring,
+                   "t_states": self.t_states.cpu(), "rollouts": self._rollouts, "global_steps": self.global_steps,
+                   "stats_host": {k: float(v) for k, v in self._stats_host.items()},
+                   "stats5": None if self._stats_stream is None else self._stats5.cpu()})
+        return sd
+
+    def load_state_dict(self, sd: dict):
+        if not self.native:
+            raise NotImplementedError("only device-resident env batches can be restored")
+        b = self.batch
+        for k in ("kind", "num_envs", "ring"):
+            if sd[k] != getattr(b, k):
+                raise ValueError(f"checkpoint env batch has {k}={sd[k]}, this run has {getattr(b, k)}")
+        for name in _BATCH_TENSORS:
+            getattr(b, name).copy_(sd[name])
+        b.seed, b.env_base = int(sd["seed"]), int(sd["env_base"])
+        self.t_states = sd["t_states"].to(self.device)
+        self._rollouts, self.global_steps = int(sd["rollouts"]), int(sd["global_steps"])
+        self._stats_host = {k: np.float32(v) if k == "max" else v for k, v in sd["stats_host"].items()}
+        self._stats_dev = None
+        if sd["stats5"] is not None:                 # the running max lives in this device buffer
+            if self._stats_stream is None:
+                self._stats_stream = torch.cuda.Stream(device=b.device)
+                self._stats_cnt = torch.zeros(1, dtype=torch.int64, device=b.device)
+                self._stats_keys = torch.empty((2, b.num_envs * b.ring), dtype=torch.float32, device=b.device)
+            self._stats5 = sd["stats5"].to(b.device)
+        torch.cuda.synchronize()
+
     def _rollout_host(self):
         """Host-stepped gym envs; the control flow of reference src/ppo.py:320-398 with the
         per-actor bookkeeping done on whole [N] arrays."""
@@ -485,6 +528,7 @@ class PPO:
         # where the MLP and the rollout buffers live; the kernels always run on the HIP device
         self.device = "cuda" if (use_gpu and torch.cuda.is_available()) else "cpu"
         self.updates = 0
+        self._lr_anneal = 1.0
         self.last_metrics: dict = {}
         # Discrete heads: log-prob, entropy, ratio and losses in one kernel (ppo_loss_logits_fwd_bwd);
         # False keeps torch.distributions.Categorical in front of ppo_loss_fwd_bwd.
@@ -645,12 +689,43 @@ class PPO:
             with open(path, "a") as f:
                 f.write(json.dumps({"step": step, **metrics}) + "\n")
 
+    # -- checkpoint / resume (absent in the reference) ------------------------------
+    def state_dict(self) -> dict:
+        return {"agent": self.agent.state_dict(), "pi_optimizer": self.pi_optimizer.state_dict(),
+                "va_optimizer": self.va_optimizer.state_dict(), "vec_env": self.vec_env.state_dict(),
+                "updates": self.updates, "lr_anneal": self._lr_anneal,
+                "rng_cpu": torch.get_rng_state(),
+                "rng_cuda": torch.cuda.get_rng_state() if torch.cuda.is_available() else None}
+
+    def load_state_dict(self, sd: dict):
+        self.agent.load_state_dict(sd["agent"])
+        self.pi_optimizer.load_state_dict(sd["pi_optimizer"])
+        self.va_optimizer.load_state_dict(sd["va_optimizer"])
+        self.vec_env.load_state_dict(sd["vec_env"])
+        self.updates, self._lr_anneal = int(sd["updates"]), float(sd["lr_anneal"])
+        torch.set_rng_state(sd["rng_cpu"])
+        if sd["rng_cuda"] is not None and torch.cuda.is_available():
+            torch.cuda.set_rng_state(sd["rng_cuda"])
+
+    def save_checkpoint(self, path: str):
+        """One file per rank under data parallelism (each rank owns its env shard)."""
+        tmp = f"{path}.tmp"
+        torch.save(self.state_dict(), tmp)
+        os.replace(tmp, path)
+
+    def load_checkpoint(self, path: str):
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+
     # -- training loop ----------------------------------------------------------------------
     def train(self, env_fn, num_updates, num_envs, steps_per_env, num_epochs, batch_size, critic_coef,
               entropy_coef, clip_ratio, max_grad_norm, learning_rate, target_div=None, render_every=0,
-              render_fps=0.0, early_stop_reward=None):
+              render_fps=0.0, early_stop_reward=None, checkpoint_path=None, checkpoint_every=0,
+              resume_from=None):
         """reference src/ppo.py:675-763.  Under torch.distributed (one process per GPU) `num_envs`
-        is the GLOBAL env count; every rank owns num_envs / world_size of them."""
+        is the GLOBAL env count; every rank owns num_envs / world_size of them.
+        checkpoint_path / checkpoint_every / resume_from are additions (the reference cannot resume):
+        a resumed run continues bit for bit where the saved one stopped (rank r uses `<path>.rank<r>`
+        when world_size > 1)."""
         test_env = env_fn()
         test_obs_shape = np.asarray(test_env.reset()[0]).shape
         state_space = test_env.observation_space
@@ -671,16 +746,23 @@ class PPO:
         # both optimisers cover ALL parameters, as in the reference (:732-733)
         self.pi_optimizer = optim.Adam(self.agent.parameters(), lr=learning_rate, eps=1e-5)
         self.va_optimizer = optim.Adam(self.agent.parameters(), lr=learning_rate, eps=1e-5)
-        lr_anneal = 1.0
+        self._lr_anneal = 1.0
+        suffix = f".rank{rank}" if world > 1 else ""
+        if resume_from:
+            self.load_checkpoint(resume_from + suffix)
 
-        it = range(num_updates)
-        pbar = _tqdm.trange(num_updates, leave=True) if (_tqdm is not None and rank == 0) else None
+        it = range(self.updates, num_updates)
+        pbar = (_tqdm.trange(self.updates, num_updates, leave=True)
+                if (_tqdm is not None and rank == 0) else None)
         for _update in (pbar if pbar is not None else it):
             pi_loss, va_loss, entropy, clip_frac, kl_div, roll_return, ep_return_max = self.train_step(
-                num_epochs, batch_size, critic_coef, entropy_coef, clip_ratio, target_div, max_grad_norm, lr_anneal)
+                num_epochs, batch_size, critic_coef, entropy_coef, clip_ratio, target_div, max_grad_norm,
+                self._lr_anneal)
             if num_updates > 1:                            # the reference divides by zero here for 1 update (:748)
-                lr_anneal -= 0.999 / (num_updates - 1)
+                self._lr_anneal -= 0.999 / (num_updates - 1)
             self.updates += 1
+            if checkpoint_path and checkpoint_every > 0 and self.updates % checkpoint_every == 0:
+                self.save_checkpoint(checkpoint_path + suffix)
             if pbar is not None:
                 pbar.set_postfix({"pi_loss": f"{pi_loss:.3f}", "va_loss": f"{va_loss:.3f}",
                                   "entropy": f"{entropy:.3f}", "return": f"{roll_return:.3f}",

@@ -4,7 +4,9 @@
         <num_epochs> <batch_size> <critic_coef> <entropy_coef> <clip_ratio> <max_grad_norm>
         <learning_rate> <discount_factor> <gae_factor> <norm_adv> <clip_va_loss> <conv_net>
         <joint_network> [--use_gpu 1] [--target_div F] [--render_every N] [--render_fps F]
-        [--early_stop_reward F]
+        [--early_stop_reward F] [--checkpoint_path P --checkpoint_every N] [--resume_from P]
+
+The last three options are additions (the reference keeps no checkpoints).
 
 `env_module` is looked up first as given (the reference's behaviour: any importable module
 with a `train_fn`), then inside this package (env_cartpole, env_acrobot).  Under torchrun
@@ -34,6 +36,9 @@ def build_parser():
     p.add_argument("--render_every", default=0, type=int)
     p.add_argument("--render_fps", default=0.0, type=float)
     p.add_argument("--early_stop_reward", default=None, type=float)
+    p.add_argument("--checkpoint_path", default=None, type=str)
+    p.add_argument("--checkpoint_every", default=0, type=int)
+    p.add_argument("--resume_from", default=None, type=str)
     return p
 
 
@@ -54,7 +59,9 @@ def main(argv=None):
                 args.joint_network, args.use_gpu, project_name=args.experiment_name)
     agent.train(env_fn, args.num_updates, args.num_envs, args.steps_per_env, args.num_epochs, args.batch_size,
                 args.critic_coef, args.entropy_coef, args.clip_ratio, args.max_grad_norm, args.learning_rate,
-                args.target_div, args.render_every, args.render_fps, args.early_stop_reward)
+                args.target_div, args.render_every, args.render_fps, args.early_stop_reward,
+                checkpoint_path=args.checkpoint_path, checkpoint_every=args.checkpoint_every,
+                resume_from=args.resume_from)
     return agent
 
 

@@ -176,6 +176,53 @@ def test_cli_plumbing_config1():
     assert agent.updates == 2 and agent.vec_env.num_envs == 8 and agent.last_metrics["utils/env_steps_per_sec"] > 0
 
 
+@pytest.mark.parametrize("joint", [1, 0])
+def test_checkpoint_resume_is_bit_identical(tmp_path, monkeypatch, joint):
+    """Train 6 updates straight vs 3 updates -> checkpoint -> fresh process state -> resume 3 more:
+    identical parameters, env state and metrics (the reference has no checkpointing)."""
+    from ppo_amd import ppo_cli
+    monkeypatch.setenv("PPO_AMD_SEED", "17")      # env seed of the first run (unseeded runs draw os.urandom)
+    base = f"ck env_cartpole 6 64 32 2 512 0.5 0.01 0.2 0.5 3e-4 0.99 0.95 1 1 0 {joint} --use_gpu 1".split()
+
+    def run(extra, seed=5):
+        torch.manual_seed(seed)
+        torch.cuda.manual_seed(seed)
+        return ppo_cli.main(base + extra)
+
+    straight = run([])
+    ck3 = str(tmp_path / "ck3.pt")
+
+    class Stop(Exception):
+        pass
+
+    # stop a run right after its update-3 checkpoint, as a killed job would
+    from ppo_amd import PPO
+    orig = PPO.save_checkpoint
+
+    def save_and_stop(self, path):
+        orig(self, path)
+        raise Stop
+
+    PPO.save_checkpoint = save_and_stop
+    try:
+        with pytest.raises(Stop):
+            run(["--checkpoint_path", ck3, "--checkpoint_every", "3"])
+    finally:
+        PPO.save_checkpoint = orig
+    torch.manual_seed(999)             # a resumed run depends on neither the ambient RNG state ...
+    torch.cuda.manual_seed(999)
+    monkeypatch.setenv("PPO_AMD_SEED", "4242")    # ... nor the env seed of the new process
+    resumed = ppo_cli.main(base + ["--resume_from", ck3])
+    assert resumed.updates == 6
+    for a, b in zip(straight.agent.parameters(), resumed.agent.parameters()):
+        assert torch.equal(a, b)
+    for name in ("state", "elapsed", "episode", "ep_ret", "ring_cnt", "ret_ring"):
+        assert torch.equal(getattr(straight.vec_env.batch, name), getattr(resumed.vec_env.batch, name)), name
+    for k, v in straight.last_metrics.items():
+        if not k.endswith("_per_sec"):
+            assert resumed.last_metrics[k] == v or (np.isnan(v) and np.isnan(resumed.last_metrics[k])), k
+
+
 def test_episode_statistics_match_numpy_percentiles():
     """ppo_episode_keys + sort + ppo_episode_stats vs the reference's formulas (src/ppo.py:407-417):
     np.max / np.percentile([5, 50, 95]) over the concatenated return deques, np.percentile(50) of lengths."""
