@@ -225,18 +225,16 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
  * Episode statistics from the device rings.  Replaces the tail of SyncVecEnv.rollout
  * (src/ppo.py:404-417): np.concatenate of every env's return_queue / length_queue, np.max,
  * np.percentile(returns, [5, 50, 95]) and np.percentile(lengths, 50).
- * Step 1, ppo_episode_keys: flatten the rings into two f32 key arrays [N*ring] (+inf in unused
- * slots) and count the valid entries into *count (u64, device; zeroed by the call).
- * Step 2 (caller): sort both key arrays ascending.
- * Step 3, ppo_episode_stats: stats5 (device f64[5]) = {running max, p5, p50, p95 of the returns,
- * median length}, "linear" interpolation like np.percentile; left untouched while *count == 0, so
- * initialise stats5 to NaN (src/ppo.py:250-254).
+ * stats5 (device f64[5]) = {running max, p5, p50, p95 of the returns, median length}, "linear"
+ * interpolation like np.percentile, exact (a radix select over the valid ring slots; nothing is
+ * sorted).  Left untouched while no episode has finished, so initialise stats5 to NaN
+ * (src/ppo.py:250-254); stats5[0] is a running maximum across calls (:408-410).
+ * workspace: ppo_episode_stats_workspace_bytes() bytes of device memory, 8-byte aligned.
  */
-int ppo_episode_keys(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring,
-                     int N, float *ret_key, float *len_key, unsigned long long *count,
-                     void *stream);
-int ppo_episode_stats(const float *ret_sorted, const float *len_sorted,
-                      const unsigned long long *count, double *stats5, void *stream);
+size_t ppo_episode_stats_workspace_bytes(void);
+int ppo_episode_stats(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring,
+                      int N, double *stats5, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,23 +8,28 @@
 // inter-lane or inter-launch synchronisation exists.  The per-step-launch path (torch MLP + env.hip)
 // spends ~85 us of kernel time and ~150 us of wall per time step at N = 65536, almost all of it
 // in launch gaps and in streaming 16 MB hidden activations through HBM for a 0.6 GFLOP problem.
-// Here the activations never leave the CU.
+// Here the activations never leave the register file.
 //
-// Per wave (64 envs) and step: the two 64-wide tanh layers run on the matrix cores with
+// Per wave (64 envs) and step the two 64-wide tanh layers run on the matrix cores with
 // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate -- exactly a k-ordered fmaf chain, so no precision
-// is given up); activations live in a wave-private LDS tile [unit][env], weights are staged once
-// per workgroup into LDS pre-arranged as MFMA A-operand fragments, so ONE conflict-free
-// ds_read_b32 hands the wave 64 distinct weights.  That operand delivery is the point of using
-// MFMA here, not its FLOP rate (equal to v_pk_fma_f32): two VALU formulations were measured first
-//   - weights as SGPR operands via the scalar cache: 80 live SGPRs spill to VGPR lanes, the 17 KB
-//     network thrashes the 16 KB scalar cache                                  5.4 ms / rollout
-//   - weights broadcast from LDS with ds_read_b128: every wave re-reads the whole matrix through
-//     the CU's one LDS port, 4 cycles per 4 weights                            2.9 ms / rollout
-// Heads, sampling (Philox) and the fp64 env physics of env_core.h run lane = env on the VALU.
-// After the initial weight staging no barrier exists: waves never exchange data.
+// is given up).  The layers are CHAINED IN REGISTERS: the D layout of one 32x32 tile (lane = env
+// l & 31, register r = unit (r&3) + 8 (r>>2) + 4 (l>>5)) is, register by register, a valid B
+// operand of the next layer (lane = (k half l >> 5, env l & 31)) for the k-pair
+// (unit(r), unit(r) + 4) -- so the next layer's weights are packed on the host in THAT k order and
+// an accumulator register goes straight from tanh into the next MFMA.  No LDS round trip, no
+// shuffles.  The whole network (72 A-operand fragments + the per-lane head weights) stays in the
+// 512-entry register file for all T steps (one wave per SIMD), so the time-step loop of the joint
+// net touches no LDS at all.  Earlier formulations, measured at N = 65536, T = 128, joint net:
+//   - weights as SGPR operands via the scalar cache (VALU dot products)          5.4 ms / rollout
+//   - weights broadcast from LDS with ds_read_b128 (VALU)                         2.9 ms
+//   - MFMA with weights and a [unit][env] activation tile in LDS                  1.56 ms
+// The heads are per-lane partial dot products over the 32 units a lane holds, completed with one
+// v_permlane32_swap + add, which also hands every lane the result of ITS env (lane = env again for
+// sampling (Philox) and the fp64 env physics of env_core.h).
 //
-// Bound: MFMA issue (144 x 64 cycles per step, joint net) + ~2k VALU instructions per step.
-// HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done, trunc).
+// Bound: MFMA issue (144 x 64 cycles per step, joint net) + the VALU work that does not fit in
+// its shadow.  HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done,
+// trunc).
 #include "env_core.h"
 #include <cstdlib>
 
@@ -50,18 +55,20 @@ struct RolloutArgs {
 };
 
 // Packed parameter layout (floats), built by ppo_amd.ops.pack_dense_agent:
-//   backbone(pi): F1[S1][2][64]  F2[33][2][64]      MFMA A-operand fragments, see frag()
+//   backbone(pi): F1[S1][2][64]  F2[33][2][64]      MFMA A-operand fragments
 //   backbone(va): same (split nets only)
-//   heads:        HP[64][4] (logit weights per hidden unit, zero padded)  bp[4]
-//                 HV[64]   (critic weights)                                bc[1]
-// frag(): a Linear(K -> 64) layer y = W x + b is evaluated as 1 + K/2 k-steps of
-// v_mfma_f32_32x32x2_f32 per 32-output tile o.  Lane l of k-step s holds
-//   s = 0 : (l < 32) ? b[32 o + l] : 0                 (paired with the constant B row [1; 0])
-//   s > 0 : W[32 o + (l & 31)][2 (s - 1) + (l >> 5)]
-// so one conflict-free ds_read_b32 delivers 64 distinct weights to the wave.
+//   heads:        HL[4][2][16][64]  per-lane head weights, outputs j = 0..2 logits (zero padded),
+//                 j = 3 critic;  bias4[4] = policy bias (zero padded), critic bias
+// unit(o, r, h) = 32 o + (r & 3) + 8 (r >> 2) + 4 h is the hidden unit that register r of output
+// tile o holds in lane half h (the MFMA D layout).  A Linear(K -> 64) layer y = W x + b is 1 + K/2
+// k-steps per 32-output tile o; lane l of k-step s holds
+//   s = 0           : (l < 32) ? b[32 o + l] : 0                   (paired with the B row [1; 0])
+//   layer 1, s > 0  : W[32 o + (l & 31)][2 (s - 1) + (l >> 5)]     (inputs in natural order)
+//   layer 2, s > 0  : W[32 o + (l & 31)][unit(o_in, r_in, l >> 5)],  s = 1 + 16 o_in + r_in
+//   HL[j][o][r][l]  : Whead_j[unit(o, r, l >> 5)]
 __host__ __device__ constexpr int ksteps(int k_in) { return 1 + (k_in + 1) / 2; }
 __host__ __device__ constexpr int backbone_floats(int obs) { return (ksteps(obs) + ksteps(H)) * 2 * 64; }
-constexpr int HEAD_FLOATS = H * 4 + 4 + H + 1;
+constexpr int HEAD_FLOATS = 4 * 2 * 16 * 64 + 4;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -75,55 +82,113 @@ __device__ __forceinline__ float fast_tanh(float x)
     return __builtin_copysignf(r, x);
 }
 
-// One dense layer K_IN -> 64 with tanh for the 64 envs of this wave, in place in the wave's LDS
-// tile hw[unit][env]: reads rows 0..K_IN-1, writes rows 0..63.
-//   A operand (weights): lane l = (out row l & 31, k half l >> 5)  -> frag rows above
-//   B operand (inputs):  lane l = (k half l >> 5, env l & 31)       -> hw[(2(s-1) + half)][32 e + (l & 31)]
-//   D (32 out x 32 env): lane l holds env l & 31, register r holds out row (r&3) + 8 (r>>2) + 4 (l>>5)
-// The bias k-step comes first, so every output is the fmaf chain b, +w0 x0, +w1 x1, ... in input
-// order (f32 MFMA is exactly a k-ordered fmaf chain on gfx950).
-template <int K_IN>
-__device__ __forceinline__ void dense_tanh_mfma(float *hw, const float *frag, int lane)
+// lanes 32..63 of a <-> lanes 0..31 of b.  (The compiler builtin for this instruction returns its
+// second result wrong in ROCm 7.2's hipcc, hence the asm; the s_nops cover the VALU-write ->
+// permlane-read wait states the assembler does not insert for inline asm.)
+__device__ __forceinline__ void swap_halves(float &a, float &b)
 {
-    constexpr int S = ksteps(K_IN);
-    const int half = lane >> 5, l31 = lane & 31;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[o][e][r] = 0.0f;
-    {
-        const float one = half == 0 ? 1.0f : 0.0f;
-        const float a0 = frag[lane], a1 = frag[64 + lane];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, one, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, one, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, one, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, one, acc[1][1], 0, 0, 0);
-    }
-    const float *brow = hw + half * 64 + l31;
-#pragma unroll 4
-    for (int s = 1; s < S; ++s) {
-        const float a0 = frag[(s * 2 + 0) * 64 + lane], a1 = frag[(s * 2 + 1) * 64 + lane];
-        const float b0 = brow[(s - 1) * 128], b1 = brow[(s - 1) * 128 + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int out = 32 * o + (r & 3) + 8 * (r >> 2) + 4 * half;
-                hw[out * 64 + 32 * e + l31] = fast_tanh(acc[o][e][r]);
-            }
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 
-constexpr int ROLLOUT_BLOCK = 256;  // 4 waves share one LDS copy of the network
+// A-operand fragments of one backbone held in registers (all indices are compile-time constants
+// after unrolling) or read from LDS (pointer already offset by the lane).
+template <int S> struct RegFrags {
+    float a[S][2];
+    __device__ __forceinline__ void load(const float *g, int lane)
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            a[s][0] = g[(s * 2 + 0) * 64 + lane];
+            a[s][1] = g[(s * 2 + 1) * 64 + lane];
+        }
+    }
+    __device__ __forceinline__ float get(int s, int o) const { return a[s][o]; }
+};
+struct LdsFrags {
+    const float *p;
+    __device__ __forceinline__ float get(int s, int o) const { return p[(s * 2 + o) * 64]; }
+};
+
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
+}
+
+#define PPO_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
+
+// Both tanh layers and the heads for the 64 envs of this wave.  obs: this lane's env (lane = env).
+// out[j]: head j of this lane's env, bias not yet added (j < A logits if DO_P, j = 3 critic if DO_V).
+template <int OBS, int A, bool DO_P, bool DO_V, class W1, class W2>
+__device__ __forceinline__ void net_forward(const float (&obs)[6], const W1 &w1, const W2 &w2,
+                                            const float (&hl)[4][2][16], int half, float (&out)[4])
+{
+    constexpr int S1 = ksteps(OBS);
+    const float one = half == 0 ? 1.0f : 0.0f;
+    // ---- layer 1: bias k-step, then input pairs; one half-swap turns (obs[2k], obs[2k+1]) of the
+    // 64 envs into the B fragments of env tile 0 and env tile 1.
+    f32x16 h1[2][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) h1[o][e] = PPO_MFMA(w1.get(0, o), one, zero16());
+#pragma unroll
+    for (int s = 1; s < S1; ++s) {
+        float b0 = obs[2 * (s - 1)], b1 = obs[2 * (s - 1) + 1];
+        swap_halves(b0, b1);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            h1[o][0] = PPO_MFMA(w1.get(s, o), b0, h1[o][0]);
+            h1[o][1] = PPO_MFMA(w1.get(s, o), b1, h1[o][1]);
+        }
+    }
+    // ---- layer 2, one output tile at a time: tanh(h1) registers are the B operands as they are.
+    // The heads of output tile 0 have no dependence on tile 1's MFMAs and fill their issue gaps.
+    float p[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j][0] = p[j][1] = 0.0f;
+    f32x16 h2[2][2];
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+        h2[op][0] = PPO_MFMA(w2.get(0, op), one, zero16());
+        h2[op][1] = PPO_MFMA(w2.get(0, op), one, zero16());
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (op == 0) {
+                    h1[o][0][r] = fast_tanh(h1[o][0][r]);
+                    h1[o][1][r] = fast_tanh(h1[o][1][r]);
+                }
+                const float w = w2.get(1 + 16 * o + r, op);
+                h2[op][0] = PPO_MFMA(w, h1[o][0][r], h2[op][0]);
+                h2[op][1] = PPO_MFMA(w, h1[o][1][r], h2[op][1]);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float h = fast_tanh(h2[op][e][r]);
+                if (DO_P) {
+#pragma unroll
+                    for (int j = 0; j < A; ++j) p[j][e] = __builtin_fmaf(h, hl[j][op][r], p[j][e]);
+                }
+                if (DO_V) p[3][e] = __builtin_fmaf(h, hl[3][op][r], p[3][e]);
+            }
+    }
+    // ---- complete the dot products across the two lane halves; lane l ends with env l's result
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if ((j < A && DO_P) || (j == 3 && DO_V)) {
+            swap_halves(p[j][0], p[j][1]);
+            out[j] = p[j][0] + p[j][1];
+        }
+    }
+}
+
+constexpr int ROLLOUT_BLOCK = 256;  // 4 waves, one per SIMD
 
 template <class Env, int A, bool JOINT>
 __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const float *__restrict__ params)
@@ -131,24 +196,37 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     constexpr int OBS = Env::OBS;
     static_assert(OBS % 2 == 0 && A <= 3, "fragment layout assumes an even input width and <= 3 actions");
     constexpr int NB = backbone_floats(OBS);
-    constexpr int NP = NB * (JOINT ? 1 : 2) + HEAD_FLOATS;
-    constexpr int NP_PAD = (NP + 3) & ~3;
-    __shared__ __attribute__((aligned(16))) float sW[NP_PAD];                         // the network
-    __shared__ __attribute__((aligned(16))) float sH[(ROLLOUT_BLOCK / 64) * H * 64];  // [wave][unit][env]
-    for (int k = threadIdx.x; k < NP; k += ROLLOUT_BLOCK) sW[k] = params[k];
-    __syncthreads();                               // the only barrier: waves are independent from here on
+    constexpr int S1 = ksteps(OBS), S2 = ksteps(H);
 
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
     const size_t n = (size_t)blockIdx.x * ROLLOUT_BLOCK + threadIdx.x;
     // Tail lanes (n >= N) stay: MFMA needs all 64 lanes.  They shadow env N-1 and never store.
     const bool live = n < (size_t)a.env.N;
     const size_t nn = live ? n : (size_t)a.env.N - 1;
-    float *hw = sH + (threadIdx.x >> 6) * (H * 64);   // this wave's [unit][env] tile
-    float *hl = hw + lane;                            // this lane's env column
 
-    const float *F1 = sW, *F2 = F1 + ksteps(OBS) * 128;
-    const float *G1 = sW + NB, *G2 = G1 + ksteps(OBS) * 128;      // value backbone (split nets)
-    const float *HP = sW + NB * (JOINT ? 1 : 2), *bp = HP + H * 4, *HV = bp + 4, *bc = HV + H;
+    // ---- the network: policy (or joint) backbone in registers for the whole rollout; the value
+    // backbone of split nets is shared by the block's waves through LDS.
+    RegFrags<S1> P1;
+    RegFrags<S2> P2;
+    P1.load(params, lane);
+    P2.load(params + S1 * 128, lane);
+    __shared__ float sV[JOINT ? 1 : NB];
+    if (!JOINT) {
+        for (int k = threadIdx.x; k < NB; k += ROLLOUT_BLOCK) sV[k] = params[NB + k];
+        __syncthreads();                           // the only barrier: waves are independent from here on
+    }
+    const LdsFrags V1{sV + lane}, V2{sV + (JOINT ? 0 : S1 * 128) + lane};
+    const float *heads = params + NB * (JOINT ? 1 : 2);
+    float hl[4][2][16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hl[j][o][r] = (j < A || j == 3) ? heads[((j * 2 + o) * 16 + r) * 64 + lane] : 0.0f;
+    float bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = heads[4 * 2 * 16 * 64 + j];
 
     EnvRegs e;
     load_env(e, a.env, nn);
@@ -158,35 +236,20 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 
     const size_t N = (size_t)a.env.N;
     for (int t = 0; t < a.T; ++t) {
-        // ---- policy backbone (src/ppo.py:126-131) on the matrix cores
-#pragma unroll
-        for (int k = 0; k < OBS; ++k) hl[k * 64] = obs[k];
+        // ---- backbone(s) + heads (src/ppo.py:126-145, :174-182)
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
         if (!(a.ablate & 1)) {
-            dense_tanh_mfma<OBS>(hw, F1, lane);
-            dense_tanh_mfma<H>(hw, F2, lane);
+            if (JOINT) {
+                net_forward<OBS, A, true, true>(obs, P1, P2, hl, half, out);
+            } else {
+                net_forward<OBS, A, true, false>(obs, P1, P2, hl, half, out);
+                net_forward<OBS, A, false, true>(obs, V1, V2, hl, half, out);
+            }
         }
-
-        // ---- heads (:140, :145): lane = env again, 64-term fmaf chains in unit order
-        float lg[A], value = bc[0];
+        float lg[A];
 #pragma unroll
-        for (int j = 0; j < A; ++j) lg[j] = bp[j];
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) {
-            const float h = hl[k * 64];
-            const float4 w = *reinterpret_cast<const float4 *>(HP + k * 4);
-            lg[0] = __builtin_fmaf(h, w.x, lg[0]);
-            lg[1] = __builtin_fmaf(h, w.y, lg[1]);
-            if (A > 2) lg[2] = __builtin_fmaf(h, w.z, lg[2]);
-            if (JOINT) value = __builtin_fmaf(h, HV[k], value);
-        }
-        if (!JOINT) {                              // separate value backbone (:132-138, :179-182)
-#pragma unroll
-            for (int k = 0; k < OBS; ++k) hl[k * 64] = obs[k];
-            dense_tanh_mfma<OBS>(hw, G1, lane);
-            dense_tanh_mfma<H>(hw, G2, lane);
-#pragma unroll 8
-            for (int k = 0; k < H; ++k) value = __builtin_fmaf(hl[k * 64], HV[k], value);
-        }
+        for (int j = 0; j < A; ++j) lg[j] = out[j] + bias4[j];
+        const float value = out[3] + bias4[3];
 
         int action;
         float logp;
@@ -224,14 +287,13 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         // at the forced last step, ~1/8 of the other steps for a policy that reaches the 500-step limit).
         const bool need_ev = a.ev_dense != nullptr && live && o.trunc > 0;
         if (__any(need_ev)) {
+            float tobs[6];
 #pragma unroll
-            for (int k = 0; k < OBS; ++k) hl[k * 64] = need_ev ? o.term[k] : obs[k];
-            dense_tanh_mfma<OBS>(hw, JOINT ? F1 : G1, lane);
-            dense_tanh_mfma<H>(hw, JOINT ? F2 : G2, lane);
-            float ev = bc[0];
-#pragma unroll 8
-            for (int k = 0; k < H; ++k) ev = __builtin_fmaf(hl[k * 64], HV[k], ev);
-            if (need_ev) a.ev_dense[(size_t)t * N + n] = ev;
+            for (int k = 0; k < 6; ++k) tobs[k] = need_ev ? o.term[k] : obs[k];
+            float ev[4] = {0.f, 0.f, 0.f, 0.f};
+            if (JOINT) net_forward<OBS, A, false, true>(tobs, P1, P2, hl, half, ev);
+            else net_forward<OBS, A, false, true>(tobs, V1, V2, hl, half, ev);
+            if (need_ev) a.ev_dense[(size_t)t * N + n] = ev[3] + bias4[3];
         }
         if (live) {
 #pragma unroll

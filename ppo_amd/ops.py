@@ -253,40 +253,65 @@ def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int
 
 
 # --------------------------------------------------------------------------- fused rollout
-def _mfma_frags(weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+def _d_layout_unit(o, r, half):
+    """Hidden unit held by register r of output tile o in lane half `half` of the
+    v_mfma_f32_32x32x2_f32 D layout (rollout.hip: unit(o, r, h))."""
+    return 32 * o + (r & 3) + 8 * (r >> 2) + 4 * half
+
+
+def _mfma_frags(weight: torch.Tensor, bias: torch.Tensor, chained: bool = False) -> torch.Tensor:
     """Linear(K -> 64) as v_mfma_f32_32x32x2_f32 A-operand fragments [1 + K/2, 2, 64]
-    (layout documented at frag() in ppo_amd/csrc/rollout.hip)."""
+    (layout documented in ppo_amd/csrc/rollout.hip).  chained=True: K = 64 inputs arrive as the
+    previous layer's accumulator registers, i.e. k-step 1 + 16 o + r pairs the units
+    unit(o, r, 0) and unit(o, r, 1)."""
     W = weight.detach().to(torch.float32)
     K = W.shape[1]
     if K % 2:
         W = torch.cat([W, W.new_zeros(64, 1)], dim=1)
         K += 1
-    lane = torch.arange(64, device=W.device)
+    dev = W.device
+    lane = torch.arange(64, device=dev)
     half, l31 = lane >> 5, lane & 31
+    s = torch.arange(K // 2, device=dev)
+    if chained:
+        assert K == 64
+        o_in, r_in = s // 16, s % 16
+        col = _d_layout_unit(o_in[:, None], r_in[:, None], half[None, :])    # [32 k-steps, 64 lanes]
+    else:
+        col = 2 * s[:, None] + half[None, :]
     frag = W.new_zeros(1 + K // 2, 2, 64)
     for o in range(2):
         frag[0, o] = torch.where(half == 0, bias.detach().to(torch.float32)[32 * o + l31], W.new_zeros(()))
-        s = torch.arange(K // 2, device=W.device)
-        frag[1:, o] = W[(32 * o + l31)[None, :], 2 * s[:, None] + half[None, :]]
+        frag[1:, o] = W[(32 * o + l31)[None, :], col]
     return frag.reshape(-1)
 
 
 def pack_dense_agent(agent) -> torch.Tensor:
     """Flatten a dense Agent's parameters into the layout k_rollout reads (rollout.hip): per
-    backbone the MFMA fragments of both tanh layers, then the heads as HP[64][4] (logit weights per
-    hidden unit, zero padded), bp[4], HV[64] (critic weights), bc[1]."""
+    backbone the MFMA fragments of both tanh layers (the second in register-chained k order), then
+    the per-lane head weights HL[4][2][16][64] (j = 0..2 logits zero padded, j = 3 critic) and
+    bias4 = (policy bias zero padded to 3, critic bias)."""
     def backbone(seq):
-        return [_mfma_frags(seq[0].weight, seq[0].bias), _mfma_frags(seq[2].weight, seq[2].bias)]
+        return [_mfma_frags(seq[0].weight, seq[0].bias), _mfma_frags(seq[2].weight, seq[2].bias, chained=True)]
     with torch.no_grad():
         parts = backbone(agent.pi_backbone)
         if not agent.joint_net:
             parts += backbone(agent.va_backbone)
         A = agent.policy.weight.shape[0]
-        hp = agent.policy.weight.new_zeros(64, 4)
-        hp[:, :A] = agent.policy.weight.t()
-        bp = agent.policy.bias.new_zeros(4)
-        bp[:A] = agent.policy.bias
-        parts += [hp.reshape(-1), bp, agent.critic.weight.reshape(-1), agent.critic.bias]
+        assert A <= 3
+        dev = agent.policy.weight.device
+        wh = agent.policy.weight.new_zeros(4, 64)
+        wh[:A] = agent.policy.weight
+        wh[3] = agent.critic.weight.reshape(-1)
+        lane = torch.arange(64, device=dev)
+        o = torch.arange(2, device=dev)[:, None, None]
+        r = torch.arange(16, device=dev)[None, :, None]
+        unit = _d_layout_unit(o, r, (lane >> 5)[None, None, :])              # [2, 16, 64]
+        hl = wh[:, unit]                                                     # [4, 2, 16, 64]
+        bias4 = agent.policy.bias.new_zeros(4)
+        bias4[:A] = agent.policy.bias
+        bias4[3] = agent.critic.bias[0]
+        parts += [hl.reshape(-1), bias4]
         return torch.cat([p.detach().to(torch.float32).reshape(-1) for p in parts]).contiguous()
 
 

@@ -179,7 +179,7 @@ class SyncVecEnv:
         nan = np.float32(np.nan)
         self._stats_host = {"max": nan, "lower": nan, "median": nan, "upper": nan, "length": nan}
         self._stats_dev = None
-        self._stats_stream = None
+        self._stats5 = None
         self._packed = (None, None)
         self._total_return = np.float32(0.0)
         self._end_states = None
@@ -358,38 +358,21 @@ class SyncVecEnv:
     def _device_episode_stats(self):
         """reference src/ppo.py:407-417 on the device rings, without a host round trip: running max,
         5/50/95 percentiles (np.percentile 'linear') of the last <=100 returns of every env, median
-        length.  Result stays a device tensor until one of the statistics attributes is read."""
+        length -- one ppo_episode_stats call (radix select, ~7 small launches on the rollout's stream).
+        The result stays a device tensor until one of the statistics attributes is read."""
         b = self.batch
-        dev = b.device
         lib = ops._lib.load()
-        # ppo_episode_keys snapshots the rings on the rollout's stream (so the next rollout may overwrite
-        # them); the sorts and ppo_episode_stats then run on a side stream: the whole-rollout kernel runs
-        # one wave per SIMD and leaves most of the chip's bandwidth idle, so they overlap with GAE and the
-        # next rollout instead of extending the step.  Four host calls in total.
-        main = torch.cuda.current_stream()
-        if self._stats_stream is None:
-            self._stats_stream = torch.cuda.Stream(device=dev)
-            self._stats5 = torch.full((5,), float("nan"), dtype=torch.float64, device=dev)
-            self._stats_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-            self._stats_keys = torch.empty((2, b.num_envs * b.ring), dtype=torch.float32, device=dev)
-        st = self._stats_stream
-        main.wait_stream(st)                            # previous statistics pass is done with the key buffers
-        keys = self._stats_keys
-        ops._lib.check(lib.ppo_episode_keys(b.ret_ring.data_ptr(), b.len_ring.data_ptr(), b.ring_cnt.data_ptr(),
-                                            b.ring, b.num_envs, keys[0].data_ptr(), keys[1].data_ptr(),
-                                            self._stats_cnt.data_ptr(), main.cuda_stream), "ppo_episode_keys")
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
-            srt = torch.sort(keys, dim=1).values        # one segmented radix sort for both key arrays
-            srt.record_stream(st)
-            ops._lib.check(lib.ppo_episode_stats(srt[0].data_ptr(), srt[1].data_ptr(), self._stats_cnt.data_ptr(),
-                                                 self._stats5.data_ptr(), st.cuda_stream), "ppo_episode_stats")
+        if self._stats5 is None:
+            self._stats5 = torch.full((5,), float("nan"), dtype=torch.float64, device=b.device)
+            self._stats_ws = torch.empty(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device=b.device)
+        ops._lib.check(lib.ppo_episode_stats(b.ret_ring.data_ptr(), b.len_ring.data_ptr(), b.ring_cnt.data_ptr(),
+                                             b.ring, b.num_envs, self._stats5.data_ptr(), self._stats_ws.data_ptr(),
+                                             self._stats_ws.numel(), ops._stream()), "ppo_episode_stats")
         self._stats_dev = self._stats5
 
     def _stat(self, key):
         if self._stats_dev is not None:                 # one device->host copy for all five values
-            with torch.cuda.stream(self._stats_stream):
-                v = self._stats_dev.cpu().numpy()
+            v = self._stats_dev.cpu().numpy()
             self._stats_dev = None
             self._stats_host = {"max": np.float32(v[0]), "lower": v[1], "median": v[2], "upper": v[3],
                                 "length": v[4]}
@@ -421,7 +404,7 @@ class SyncVecEnv:
         sd.update({"kind": b.kind, "num_envs": b.num_envs, "seed": b.seed, "env_base": b.env_base, "ring": b.ring,
                    "t_states": self.t_states.cpu(), "rollouts": self._rollouts, "global_steps": self.global_steps,
                    "stats_host": {k: float(v) for k, v in self._stats_host.items()},
-                   "stats5": None if self._stats_stream is None else self._stats5.cpu()})
+                   "stats5": None if self._stats5 is None else self._stats5.cpu()})
         return sd
 
     def load_state_dict(self, sd: dict):
@@ -439,11 +422,10 @@ class SyncVecEnv:
         self._stats_host = {k: np.float32(v) if k == "max" else v for k, v in sd["stats_host"].items()}
         self._stats_dev = None
         if sd["stats5"] is not None:                 # the running max lives in this device buffer
-            if self._stats_stream is None:
-                self._stats_stream = torch.cuda.Stream(device=b.device)
-                self._stats_cnt = torch.zeros(1, dtype=torch.int64, device=b.device)
-                self._stats_keys = torch.empty((2, b.num_envs * b.ring), dtype=torch.float32, device=b.device)
-            self._stats5 = sd["stats5"].to(b.device)
+            if self._stats5 is None:
+                self._device_episode_stats()         # allocates the buffers
+            self._stats5.copy_(sd["stats5"])
+            self._stats_dev = None
         torch.cuda.synchronize()
 
     def _rollout_host(self):

@@ -224,7 +224,7 @@ def test_checkpoint_resume_is_bit_identical(tmp_path, monkeypatch, joint):
 
 
 def test_episode_statistics_match_numpy_percentiles():
-    """ppo_episode_keys + sort + ppo_episode_stats vs the reference's formulas (src/ppo.py:407-417):
+    """ppo_episode_stats (radix select over the rings) vs the reference's formulas (src/ppo.py:407-417):
     np.max / np.percentile([5, 50, 95]) over the concatenated return deques, np.percentile(50) of lengths."""
     from ppo_amd import Agent, SyncVecEnv
     from ppo_amd.envs import DeviceEnv
@@ -253,6 +253,46 @@ def test_episode_statistics_match_numpy_percentiles():
     ve._device_episode_stats()
     assert ve.max_ep_return == np.float32(ret[valid].max())
     assert np.allclose(ve.median_ep_return, np.percentile((ret * 0.5)[valid].astype(np.float64), 50.0), rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["one", "two", "ints", "negative", "constant", "wide", "big"])
+def test_episode_statistics_select_edge_cases(case):
+    """The radix select on its hard inputs: 1-2 entries, heavy duplicates (CartPole's integer returns),
+    negative values (Acrobot), all-equal, a wide dynamic range with mixed signs, and C2 scale."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    rng = np.random.default_rng(5)
+    N = 65536 if case == "big" else 777
+    probe = DeviceEnv("cartpole")
+    agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
+    ve = SyncVecEnv(lambda: DeviceEnv("cartpole"), N, 4, 0, 0.0, agent, seed=1)
+    cnt = rng.integers(0, 300, N).astype(np.int32)
+    ret = rng.normal(0, 1, (N, 100)).astype(np.float32)
+    if case in ("one", "two"):
+        cnt[:] = 0
+        cnt[5] = 1
+        if case == "two":
+            cnt[700] = 1
+    elif case == "ints":
+        ret = rng.integers(8, 60, (N, 100)).astype(np.float32)
+    elif case == "negative":
+        ret = -rng.integers(60, 500, (N, 100)).astype(np.float32)
+    elif case == "constant":
+        ret[:] = 9.0
+    elif case == "wide":
+        ret = (rng.standard_normal((N, 100)) * 10.0 ** rng.integers(-20, 20, (N, 100))).astype(np.float32)
+        ret[3, 0] = 0.0
+        ret[4, 0] = -0.0
+    ln = rng.integers(1, 501, (N, 100)).astype(np.int32)
+    b = ve.batch
+    b.ring_cnt.copy_(torch.from_numpy(cnt)); b.ret_ring.copy_(torch.from_numpy(ret)); b.len_ring.copy_(torch.from_numpy(ln))
+    ve._device_episode_stats()
+    valid = np.arange(100)[None, :] < np.minimum(cnt, 100)[:, None]
+    want = np.percentile(ret[valid].astype(np.float64), [5.0, 50.0, 95.0])
+    got = np.array([ve.lower_ep_return, ve.median_ep_return, ve.upper_ep_return])
+    assert np.allclose(got, want, rtol=1e-12, atol=0.0), (got, want)
+    assert ve.max_ep_return == np.float32(ret[valid].max())
+    assert ve.median_ep_length == np.percentile(ln[valid], 50.0)
 
 
 class _FakeBoxEnv:
