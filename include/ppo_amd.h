@@ -35,6 +35,11 @@ extern "C" {
 #define PPO_ENV_CARTPOLE 0 /* CartPole-v1: obs_dim 4, actions {0,1}   */
 #define PPO_ENV_ACROBOT 1  /* Acrobot-v1:  obs_dim 6, actions {0,1,2} */
 
+/* How ppo_rollout_fused multiplies inside the policy / value network (the result is f32 either way) */
+#define PPO_NET_F32 0        /* v_mfma_f32_32x32x2_f32: every product an exact f32 FMA */
+#define PPO_NET_F16_SPLIT 1  /* v_mfma_f32_32x32x16_f16 on two-piece f16 splits of both operands
+                                (22 significant bits per operand, f32 accumulate): ~1.5x faster */
+
 int ppo_abi_version(void);
 
 /* Observation width of an env kind (4 / 6), or -1. */
@@ -193,7 +198,7 @@ int ppo_categorical_sample(const float *logits, int A, uint64_t seed, uint64_t e
 
 /* Number of floats in the packed dense-network parameter buffer ppo_rollout_fused reads
  * (layout in ppo_amd/csrc/rollout.hip; built by ppo_amd.ops.pack_dense_agent). */
-size_t ppo_rollout_param_floats(int kind, int joint);
+size_t ppo_rollout_param_floats(int kind, int joint, int net_mode);
 
 /*
  * A whole T-step rollout of N envs in ONE launch: per time step the dense 64-64 tanh policy /
@@ -210,12 +215,14 @@ size_t ppo_rollout_param_floats(int kind, int joint);
  *   trunc != 0 -- the end_value_dense input of ppo_gae_dense, i.e. what the reference computes
  *   with agent.get_values(end_states) (src/ppo.py:555) and reads where trunc != 0 (:478)
  * Env state arguments and rings as in ppo_env_step; row T-1 gets the forced truncation.
- * Network arithmetic is f32 FMA; values / log-probs agree with the PyTorch forward of the same
- * parameters to ~1e-6 (different summation order than hipBLASLt), not bit for bit.
+ * net_mode: PPO_NET_F32 or PPO_NET_F16_SPLIT; `params` must have been packed for that mode.
+ * Values / log-probs agree with the PyTorch f32 forward of the same parameters to ~1e-6 (different
+ * summation order than hipBLASLt; the split mode keeps 22 bits per operand), not bit for bit.
  */
 int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len,
                       uint32_t *episode, const double *reset_draw, uint64_t seed,
-                      uint64_t env_base, const float *params, int joint, uint64_t sample_step0,
+                      uint64_t env_base, const float *params, int joint, int net_mode,
+                      uint64_t sample_step0,
                       float *obs_io, float *states, int *actions, float *log_probs, float *values,
                       float *rewards, int *done, int *trunc, float *term_obs, float *ev_dense,
                       float *ret_ring, int *len_ring, int *ring_cnt, int ring, int N, int T,

@@ -159,9 +159,12 @@ template <class Env> __device__ __forceinline__ void store_obs(float *dst, size_
     }
 }
 
+// DRAWS = false compiles the caller-supplied reset stream out: a global load anywhere in the step
+// makes the compiler wait on vmcnt, which also counts the wave's stores still in flight.
+template <bool DRAWS = true>
 __device__ __forceinline__ void draw_reset(const EnvArgs &a, size_t n, uint32_t episode, double (&u)[4])
 {
-    if (a.reset_draw) {
+    if (DRAWS && a.reset_draw) {
         const double2 *p = reinterpret_cast<const double2 *>(a.reset_draw + n * 4);
         const double2 lo = p[0], hi = p[1];
         u[0] = lo.x; u[1] = lo.y; u[2] = hi.x; u[3] = hi.y;
@@ -177,6 +180,8 @@ struct EnvRegs {
     int elapsed;
     float ep_ret;
     int ep_len;
+    int ring_cnt;      // finished episodes of this env so far (next ring slot = ring_cnt % ring)
+    uint32_t episode;  // reset counter = Philox position of the next reset draw
 };
 
 struct StepOut {
@@ -188,7 +193,7 @@ struct StepOut {
 
 // One transition of env n.  Follows gymnasium env.step -> TimeLimit -> RecordEpisodeStatistics and
 // the actor loop of the reference's rollout (src/ppo.py:342-388).
-template <class Env>
+template <class Env, bool DRAWS = true>
 __device__ __forceinline__ void env_transition(EnvRegs &e, int action, const EnvArgs &a, size_t n, int is_last,
                                                StepOut &o)
 {
@@ -203,11 +208,13 @@ __device__ __forceinline__ void env_transition(EnvRegs &e, int action, const Env
     const bool ended = terminated || truncated;
     if (ended) {
         if (a.ret_ring) {
-            const int c = a.ring_cnt[n];
-            const size_t slot = n * (size_t)a.ring + (size_t)(c % a.ring);
+            // counters live in registers: a load here would make the wave wait for every store
+            // it has in flight (vmcnt counts both), once per step in practice since some env of
+            // the 64 ends an episode almost every step
+            const size_t slot = n * (size_t)a.ring + (size_t)(e.ring_cnt % a.ring);
             a.ret_ring[slot] = e.ep_ret;
             a.len_ring[slot] = e.ep_len;
-            a.ring_cnt[n] = c + 1;
+            e.ring_cnt += 1;
         }
         e.ep_ret = 0.0f;
         e.ep_len = 0;
@@ -218,11 +225,10 @@ __device__ __forceinline__ void env_transition(EnvRegs &e, int action, const Env
 #pragma unroll
         for (int k = 0; k < 6; ++k) o.term[k] = o.obs[k];
         if (can_reset) {
-            const uint32_t ep = a.episode[n];
             double u[4];
-            draw_reset(a, n, ep, u);
+            draw_reset<DRAWS>(a, n, e.episode, u);
             Env::reset(e.s, u, o.obs);
-            a.episode[n] = ep + 1;
+            e.episode += 1;
             e.elapsed = 0;
         }
     }
@@ -236,6 +242,8 @@ __device__ __forceinline__ void load_env(EnvRegs &e, const EnvArgs &a, size_t n)
     e.elapsed = a.elapsed[n];
     e.ep_ret = a.ep_ret[n];
     e.ep_len = a.ep_len[n];
+    e.ring_cnt = a.ring_cnt ? a.ring_cnt[n] : 0;
+    e.episode = a.episode[n];
 }
 
 __device__ __forceinline__ void store_env(const EnvRegs &e, const EnvArgs &a, size_t n)
@@ -246,6 +254,8 @@ __device__ __forceinline__ void store_env(const EnvRegs &e, const EnvArgs &a, si
     a.elapsed[n] = e.elapsed;
     a.ep_ret[n] = e.ep_ret;
     a.ep_len[n] = e.ep_len;
+    if (a.ring_cnt) a.ring_cnt[n] = e.ring_cnt;
+    a.episode[n] = e.episode;
 }
 
 // Categorical(logits) sample + log-prob for env `id` at policy step `step` (reference

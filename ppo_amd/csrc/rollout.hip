@@ -72,14 +72,14 @@ constexpr int HEAD_FLOATS = 4 * 2 * 16 * 64 + 4;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// tanh(x) = sign(x) * (1 - 2 / (exp(2|x|) + 1)), branch-free on the hardware exp2 / rcp units
-// (6 VALU instructions; ocml's tanhf is two divergent branches of ~20).  Absolute error < 2e-7,
-// i.e. the size of one f32 rounding of an O(1) activation; exp2 -> inf gives exactly +-1.
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units: 4 VALU instructions, no
+// branches (ocml's tanhf is two divergent branches of ~20).  exp2 overflow gives rcp(inf) = 0 ->
+// exactly 1, underflow gives rcp(1) -> exactly -1.  Absolute error < 2e-7, i.e. the size of one
+// f32 rounding of an O(1) activation.
 __device__ __forceinline__ float fast_tanh(float x)
 {
-    const float t = __builtin_amdgcn_exp2f(2.8853900817779268f * __builtin_fabsf(x));  // exp(2|x|)
-    const float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
-    return __builtin_copysignf(r, x);
+    const float t = __builtin_amdgcn_exp2f(2.8853900817779268f * x);   // exp(2x)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
 // lanes 32..63 of a <-> lanes 0..31 of b.  (The compiler builtin for this instruction returns its
@@ -144,40 +144,47 @@ __device__ __forceinline__ void net_forward(const float (&obs)[6], const W1 &w1,
             h1[o][1] = PPO_MFMA(w1.get(s, o), b1, h1[o][1]);
         }
     }
-    // ---- layer 2, one output tile at a time: tanh(h1) registers are the B operands as they are.
-    // The heads of output tile 0 have no dependence on tile 1's MFMAs and fill their issue gaps.
+    // ---- layer 2 as four 33-MFMA passes, one 32 x 32 output tile (op, e) each.  tanh(h1) registers
+    // are the B operands as they are.  The VALU work is software-pipelined into the MFMA issue
+    // shadows by hand (one sched_barrier-delimited slot per MFMA; left alone, the scheduler emits a
+    // pass's MFMAs back to back and the tanh / head work after them):
+    //   pass (0,0): tanh of the h1 registers of env tile 0, one k-step ahead of their use
+    //   pass (1,0): heads of tile (0,0)        pass (0,1): tanh of h1 env tile 1 + heads of (1,0)
+    //   pass (1,1): heads of tile (0,1)        tail:       heads of tile (1,1)
     float p[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j][0] = p[j][1] = 0.0f;
     f32x16 h2[2][2];
+    auto head = [&](int op, int e, int r) {
+        const float h = fast_tanh(h2[op][e][r]);
+        if (DO_P) {
 #pragma unroll
-    for (int op = 0; op < 2; ++op) {
-        h2[op][0] = PPO_MFMA(w2.get(0, op), one, zero16());
-        h2[op][1] = PPO_MFMA(w2.get(0, op), one, zero16());
+            for (int j = 0; j < A; ++j) p[j][e] = __builtin_fmaf(h, hl[j][op][r], p[j][e]);
+        }
+        if (DO_V) p[3][e] = __builtin_fmaf(h, hl[3][op][r], p[3][e]);
+    };
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
+    for (int e = 0; e < 2; ++e) {
+        h1[0][e][0] = fast_tanh(h1[0][e][0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (op == 0) {
-                    h1[o][0][r] = fast_tanh(h1[o][0][r]);
-                    h1[o][1][r] = fast_tanh(h1[o][1][r]);
+        for (int op = 0; op < 2; ++op) {
+            h2[op][e] = PPO_MFMA(w2.get(0, op), one, zero16());
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int o = k >> 4, r = k & 15;
+                h2[op][e] = PPO_MFMA(w2.get(1 + k, op), h1[o][e][r], h2[op][e]);
+                if (op == 0 && k + 1 < 32) h1[(k + 1) >> 4][e][(k + 1) & 15] = fast_tanh(h1[(k + 1) >> 4][e][(k + 1) & 15]);
+                if ((k & 1) == 0) {                    // heads of the tile finished one pass ago
+                    if (op == 1) head(0, e, k >> 1);
+                    else if (e == 1) head(1, 0, k >> 1);
                 }
-                const float w = w2.get(1 + 16 * o + r, op);
-                h2[op][0] = PPO_MFMA(w, h1[o][0][r], h2[op][0]);
-                h2[op][1] = PPO_MFMA(w, h1[o][1][r], h2[op][1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float h = fast_tanh(h2[op][e][r]);
-                if (DO_P) {
-#pragma unroll
-                    for (int j = 0; j < A; ++j) p[j][e] = __builtin_fmaf(h, hl[j][op][r], p[j][e]);
-                }
-                if (DO_V) p[3][e] = __builtin_fmaf(h, hl[3][op][r], p[3][e]);
-            }
+        }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) head(1, 1, r);
     // ---- complete the dot products across the two lane halves; lane l ends with env l's result
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -190,43 +197,269 @@ __device__ __forceinline__ void net_forward(const float (&obs)[6], const W1 &w1,
 
 constexpr int ROLLOUT_BLOCK = 256;  // 4 waves, one per SIMD
 
-template <class Env, int A, bool JOINT>
+// ---- network mode 0: f32 MFMA, every product an exact f32 FMA --------------------------------
+template <int OBS_, int A_, bool JOINT_> struct NetF32 {
+    static constexpr int OBS = OBS_, A = A_;
+    static constexpr bool JOINT = JOINT_;
+    static constexpr int NB = backbone_floats(OBS);
+    static constexpr int S1 = ksteps(OBS), S2 = ksteps(H);
+    static constexpr int LDS_WORDS = JOINT ? 1 : NB;
+    RegFrags<S1> P1;
+    RegFrags<S2> P2;
+    LdsFrags V1, V2;
+    float hl[4][2][16];
+    float bias4[4];
+    int half;
+
+    // policy (or joint) backbone in registers for the whole rollout; the value backbone of split
+    // nets is shared by the block's waves through LDS.
+    __device__ __forceinline__ void load(const float *__restrict__ params, float *smem, int lane)
+    {
+        half = lane >> 5;
+        P1.load(params, lane);
+        P2.load(params + S1 * 128, lane);
+        if (!JOINT) {
+            for (int k = threadIdx.x; k < NB; k += ROLLOUT_BLOCK) smem[k] = params[NB + k];
+            __syncthreads();                       // the only barrier: waves are independent from here on
+        }
+        V1.p = smem + lane;
+        V2.p = smem + (JOINT ? 0 : S1 * 128) + lane;
+        const float *heads = params + NB * (JOINT ? 1 : 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    hl[j][o][r] = (j < A || j == 3) ? heads[((j * 2 + o) * 16 + r) * 64 + lane] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias4[j] = heads[4 * 2 * 16 * 64 + j];
+    }
+    // VNET: use the value backbone (split nets)
+    template <bool DO_P, bool DO_V, bool VNET>
+    __device__ __forceinline__ void forward(const float (&obs)[6], float (&out)[4]) const
+    {
+        if (VNET) net_forward<OBS, A, DO_P, DO_V>(obs, V1, V2, hl, half, out);
+        else net_forward<OBS, A, DO_P, DO_V>(obs, P1, P2, hl, half, out);
+    }
+};
+
+// ---- network mode 1: f16 MFMA on two-piece splits (f32-grade products at 5x the MFMA rate) -----
+// v_mfma_f32_32x32x2_f32 costs 64 cycles per 2 k and does not overlap with the wave's other VALU
+// work (measured: SQ_VALU_MFMA_COEXEC_CYCLES = 0, issue gaps add up); v_mfma_f32_32x32x16_f16 does
+// 16 k in 32 cycles.  Every operand x is split as x = xh + xl / 2^11 with xh = f16(x) and
+// xl = f16((x - xh) 2^11) (the subtraction is exact), 22 significant bits in all, and a product
+// becomes xh wh + (xh wl + xl wh) / 2^11: three MFMAs into two f32 accumulators, the dropped
+// xl wl term being below 2^-22 relative.  f16 x f16 products are exact in the f32 accumulate.
+// The 2 log2(e) factor of tanh's exp2 is folded into the packed weights and biases.
+// Layouts (host: ppo_amd.ops.pack_dense_agent(mode=1)), per backbone, in 32-bit words:
+//   W1[op 2][piece 2][lane 64][4]   8 f16 per lane: k = i (both lane halves): W1[32 op + (l&31)][i], i < OBS;
+//                                   b1[32 op + (l&31)] at i = OBS (the input vector carries a 1.0 there)
+//   W2[j 4][op 2][piece 2][lane 64][4]   k-step j = 2 o_in + (r_in >> 3), element i = r_in & 7:
+//                                   W2[32 op + (l&31)][unit(o_in, r_in, l >> 5)]
+//   B2[op 2][r 16][lane 64] f32     b2[unit(op, r, l >> 5)]  (the C operand of the first k-step)
+struct Frag16 {
+    uint32_t w[4];
+};
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr float SPLIT_UP = 2048.0f, SPLIT_DOWN = 1.0f / 2048.0f;
+constexpr int BB16_W1 = 2 * 2 * 64 * 4, BB16_W2 = 4 * 2 * 2 * 64 * 4, BB16_B2 = 2 * 16 * 64;
+constexpr int BB16_WORDS = BB16_W1 + BB16_W2 + BB16_B2;
+
+__device__ __forceinline__ f32x16 mfma16(const Frag16 &a, const Frag16 &b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+// (a0, a1) -> packed f16 pairs of the high pieces and of the scaled low pieces
+__device__ __forceinline__ void split2(float a0, float a1, uint32_t &hi, uint32_t &lo)
+{
+    const auto p = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+    const float h0 = (float)p[0], h1 = (float)p[1];
+    const auto q = __builtin_amdgcn_cvt_pkrtz((a0 - h0) * SPLIT_UP, (a1 - h1) * SPLIT_UP);
+    hi = __builtin_bit_cast(uint32_t, p);
+    lo = __builtin_bit_cast(uint32_t, q);
+}
+
+// tanh of an argument already multiplied by 2 log2(e)
+__device__ __forceinline__ float tanh_prescaled(float x2)
+{
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x2) + 1.0f);
+}
+
+struct RegW16 {
+    Frag16 w1[2][2], w2[4][2][2];
+    f32x16 b2[2];
+    __device__ __forceinline__ void load(const float *__restrict__ g, int lane)
+    {
+        const uint4 *v = reinterpret_cast<const uint4 *>(g);
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const uint4 x = v[(op * 2 + pc) * 64 + lane];
+                w1[op][pc] = Frag16{{x.x, x.y, x.z, x.w}};
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int op = 0; op < 2; ++op)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    const uint4 x = v[BB16_W1 / 4 + ((j * 2 + op) * 2 + pc) * 64 + lane];
+                    w2[j][op][pc] = Frag16{{x.x, x.y, x.z, x.w}};
+                }
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b2[op][r] = g[BB16_W1 + BB16_W2 + (op * 16 + r) * 64 + lane];
+    }
+    __device__ __forceinline__ Frag16 get1(int op, int pc) const { return w1[op][pc]; }
+    __device__ __forceinline__ Frag16 get2(int j, int op, int pc) const { return w2[j][op][pc]; }
+    __device__ __forceinline__ f32x16 bias2(int op) const { return b2[op]; }
+};
+struct LdsW16 {
+    const float *p;   // LDS copy of one backbone
+    int lane;
+    __device__ __forceinline__ Frag16 rd(int idx) const
+    {
+        const uint4 x = reinterpret_cast<const uint4 *>(p)[idx * 64 + lane];
+        return Frag16{{x.x, x.y, x.z, x.w}};
+    }
+    __device__ __forceinline__ Frag16 get1(int op, int pc) const { return rd(op * 2 + pc); }
+    __device__ __forceinline__ Frag16 get2(int j, int op, int pc) const { return rd(BB16_W1 / 256 + (j * 2 + op) * 2 + pc); }
+    __device__ __forceinline__ f32x16 bias2(int op) const
+    {
+        f32x16 b;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b[r] = p[BB16_W1 + BB16_W2 + (op * 16 + r) * 64 + lane];
+        return b;
+    }
+};
+
+template <int OBS, int A, bool DO_P, bool DO_V, class W>
+__device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w, const float (&hl)[4][2][16], int half,
+                                              float (&out)[4])
+{
+    static_assert(OBS < 8, "layer-1 inputs and the bias slot must fit one 8-wide k half");
+    // ---- input pieces: (obs, 1.0 for the bias, zeros); env tile e reads them from lane half e
+    float in[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) in[k] = k < OBS ? obs[k] : (k == OBS ? 1.0f : 0.0f);
+    Frag16 ih, il;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(in[2 * i], in[2 * i + 1], ih.w[i], il.w[i]);
+    Frag16 b2h[2][4], b2l[2][4];     // layer-2 B operands: tanh(h1) pieces, [env tile][k-step]
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        Frag16 bh, bl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bh.w[i] = half == e ? ih.w[i] : 0u;
+            bl.w[i] = half == e ? il.w[i] : 0u;
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const f32x16 m = mfma16(w.get1(o, 0), bh, zero16());
+            f32x16 c = mfma16(w.get1(o, 1), bh, zero16());
+            c = mfma16(w.get1(o, 0), bl, c);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float a0 = tanh_prescaled(__builtin_fmaf(c[r], SPLIT_DOWN, m[r]));
+                const float a1 = tanh_prescaled(__builtin_fmaf(c[r + 1], SPLIT_DOWN, m[r + 1]));
+                split2(a0, a1, b2h[e][2 * o + (r >> 3)].w[(r & 7) >> 1], b2l[e][2 * o + (r >> 3)].w[(r & 7) >> 1]);
+            }
+        }
+    }
+    // ---- layer 2 + heads, one 32 x 32 output tile at a time
+    float p[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j][0] = p[j][1] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            f32x16 m = w.bias2(op), c = zero16();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m = mfma16(w.get2(j, op, 0), b2h[e][j], m);
+                c = mfma16(w.get2(j, op, 1), b2h[e][j], c);
+                c = mfma16(w.get2(j, op, 0), b2l[e][j], c);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float h = tanh_prescaled(__builtin_fmaf(c[r], SPLIT_DOWN, m[r]));
+                if (DO_P) {
+#pragma unroll
+                    for (int j = 0; j < A; ++j) p[j][e] = __builtin_fmaf(h, hl[j][op][r], p[j][e]);
+                }
+                if (DO_V) p[3][e] = __builtin_fmaf(h, hl[3][op][r], p[3][e]);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if ((j < A && DO_P) || (j == 3 && DO_V)) {
+            swap_halves(p[j][0], p[j][1]);
+            out[j] = p[j][0] + p[j][1];
+        }
+    }
+}
+
+template <int OBS_, int A_, bool JOINT_> struct NetF16 {
+    static constexpr int OBS = OBS_, A = A_;
+    static constexpr bool JOINT = JOINT_;
+    static constexpr int LDS_WORDS = JOINT ? 4 : BB16_WORDS;
+    RegW16 P;
+    LdsW16 V;
+    float hl[4][2][16];
+    float bias4[4];
+    int half;
+
+    __device__ __forceinline__ void load(const float *__restrict__ params, float *smem, int lane)
+    {
+        half = lane >> 5;
+        P.load(params, lane);
+        if (!JOINT) {
+            for (int k = threadIdx.x; k < BB16_WORDS; k += ROLLOUT_BLOCK) smem[k] = params[BB16_WORDS + k];
+            __syncthreads();
+        }
+        V.p = smem;
+        V.lane = lane;
+        const float *heads = params + BB16_WORDS * (JOINT ? 1 : 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    hl[j][o][r] = (j < A || j == 3) ? heads[((j * 2 + o) * 16 + r) * 64 + lane] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias4[j] = heads[4 * 2 * 16 * 64 + j];
+    }
+    template <bool DO_P, bool DO_V, bool VNET>
+    __device__ __forceinline__ void forward(const float (&obs)[6], float (&out)[4]) const
+    {
+        if (VNET) net_forward16<OBS, A, DO_P, DO_V>(obs, V, hl, half, out);
+        else net_forward16<OBS, A, DO_P, DO_V>(obs, P, hl, half, out);
+    }
+};
+
+template <class Env, class Net, bool DRAWS>
 __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const float *__restrict__ params)
 {
-    constexpr int OBS = Env::OBS;
+    constexpr int OBS = Env::OBS, A = Net::A;
+    constexpr bool JOINT = Net::JOINT;
     static_assert(OBS % 2 == 0 && A <= 3, "fragment layout assumes an even input width and <= 3 actions");
-    constexpr int NB = backbone_floats(OBS);
-    constexpr int S1 = ksteps(OBS), S2 = ksteps(H);
 
-    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int lane = threadIdx.x & 63;
     const size_t n = (size_t)blockIdx.x * ROLLOUT_BLOCK + threadIdx.x;
     // Tail lanes (n >= N) stay: MFMA needs all 64 lanes.  They shadow env N-1 and never store.
     const bool live = n < (size_t)a.env.N;
     const size_t nn = live ? n : (size_t)a.env.N - 1;
 
-    // ---- the network: policy (or joint) backbone in registers for the whole rollout; the value
-    // backbone of split nets is shared by the block's waves through LDS.
-    RegFrags<S1> P1;
-    RegFrags<S2> P2;
-    P1.load(params, lane);
-    P2.load(params + S1 * 128, lane);
-    __shared__ float sV[JOINT ? 1 : NB];
-    if (!JOINT) {
-        for (int k = threadIdx.x; k < NB; k += ROLLOUT_BLOCK) sV[k] = params[NB + k];
-        __syncthreads();                           // the only barrier: waves are independent from here on
-    }
-    const LdsFrags V1{sV + lane}, V2{sV + (JOINT ? 0 : S1 * 128) + lane};
-    const float *heads = params + NB * (JOINT ? 1 : 2);
-    float hl[4][2][16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hl[j][o][r] = (j < A || j == 3) ? heads[((j * 2 + o) * 16 + r) * 64 + lane] : 0.0f;
-    float bias4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bias4[j] = heads[4 * 2 * 16 * 64 + j];
+    __shared__ __attribute__((aligned(16))) float smem[Net::LDS_WORDS];
+    Net net;
+    net.load(params, smem, lane);
 
     EnvRegs e;
     load_env(e, a.env, nn);
@@ -235,21 +468,24 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     for (int k = 0; k < OBS; ++k) obs[k] = a.obs_io[nn * OBS + k];
 
     const size_t N = (size_t)a.env.N;
+    // Everything loaded above has arrived before the loop starts, so that no vmcnt wait is needed
+    // inside it: there it would also wait for the previous step's stores (vmcnt counts both).
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), other counters untouched
     for (int t = 0; t < a.T; ++t) {
         // ---- backbone(s) + heads (src/ppo.py:126-145, :174-182)
         float out[4] = {0.f, 0.f, 0.f, 0.f};
         if (!(a.ablate & 1)) {
             if (JOINT) {
-                net_forward<OBS, A, true, true>(obs, P1, P2, hl, half, out);
+                net.template forward<true, true, false>(obs, out);
             } else {
-                net_forward<OBS, A, true, false>(obs, P1, P2, hl, half, out);
-                net_forward<OBS, A, false, true>(obs, V1, V2, hl, half, out);
+                net.template forward<true, false, false>(obs, out);
+                net.template forward<false, true, true>(obs, out);
             }
         }
         float lg[A];
 #pragma unroll
-        for (int j = 0; j < A; ++j) lg[j] = out[j] + bias4[j];
-        const float value = out[3] + bias4[3];
+        for (int j = 0; j < A; ++j) lg[j] = out[j] + net.bias4[j];
+        const float value = out[3] + net.bias4[3];
 
         int action;
         float logp;
@@ -263,7 +499,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         o.trunc = 0;
         if (live) {
             if (!(a.ablate & 2)) {
-                env_transition<Env>(e, action, a.env, nn, t == a.T - 1, o);
+                env_transition<Env, DRAWS>(e, action, a.env, nn, t == a.T - 1, o);
             } else {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o.obs[k] = obs[k] + 1e-3f * (float)action;
@@ -291,9 +527,8 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 #pragma unroll
             for (int k = 0; k < 6; ++k) tobs[k] = need_ev ? o.term[k] : obs[k];
             float ev[4] = {0.f, 0.f, 0.f, 0.f};
-            if (JOINT) net_forward<OBS, A, false, true>(tobs, P1, P2, hl, half, ev);
-            else net_forward<OBS, A, false, true>(tobs, V1, V2, hl, half, ev);
-            if (need_ev) a.ev_dense[(size_t)t * N + n] = ev[3] + bias4[3];
+            net.template forward<false, true, !JOINT>(tobs, ev);
+            if (need_ev) a.ev_dense[(size_t)t * N + n] = ev[3] + net.bias4[3];
         }
         if (live) {
 #pragma unroll
@@ -306,11 +541,23 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     }
 }
 
-template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, hipStream_t s)
+template <class Env, class Net> void launch_net(const RolloutArgs &a, unsigned grid, hipStream_t s)
+{
+    if (a.env.reset_draw) hipLaunchKernelGGL((k_rollout<Env, Net, true>), dim3(grid), dim3(ROLLOUT_BLOCK), 0, s, a, a.params);
+    else hipLaunchKernelGGL((k_rollout<Env, Net, false>), dim3(grid), dim3(ROLLOUT_BLOCK), 0, s, a, a.params);
+}
+
+template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, int net_mode, hipStream_t s)
 {
     const unsigned grid = (unsigned)((a.env.N + ROLLOUT_BLOCK - 1) / ROLLOUT_BLOCK);
-    if (joint) hipLaunchKernelGGL((k_rollout<Env, A, true>), dim3(grid), dim3(ROLLOUT_BLOCK), 0, s, a, a.params);
-    else hipLaunchKernelGGL((k_rollout<Env, A, false>), dim3(grid), dim3(ROLLOUT_BLOCK), 0, s, a, a.params);
+    constexpr int OBS = Env::OBS;
+    if (net_mode == PPO_NET_F32) {
+        if (joint) launch_net<Env, NetF32<OBS, A, true>>(a, grid, s);
+        else launch_net<Env, NetF32<OBS, A, false>>(a, grid, s);
+    } else {
+        if (joint) launch_net<Env, NetF16<OBS, A, true>>(a, grid, s);
+        else launch_net<Env, NetF16<OBS, A, false>>(a, grid, s);
+    }
     return ppo_launch_status();
 }
 
@@ -318,29 +565,29 @@ template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, 
 
 extern "C" {
 
-size_t ppo_rollout_param_floats(int kind, int joint)
+size_t ppo_rollout_param_floats(int kind, int joint, int net_mode)
 {
     const int obs = ppo_env_obs_dim(kind);
-    if (obs < 0) return 0;
-    const int A = kind == PPO_ENV_CARTPOLE ? 2 : 3;
-    (void)A;
-    return (size_t)backbone_floats(obs) * (joint ? 1 : 2) + (size_t)HEAD_FLOATS;
+    if (obs < 0 || (net_mode != PPO_NET_F32 && net_mode != PPO_NET_F16_SPLIT)) return 0;
+    const size_t bb = net_mode == PPO_NET_F32 ? (size_t)backbone_floats(obs) : (size_t)BB16_WORDS;
+    return bb * (joint ? 1 : 2) + (size_t)HEAD_FLOATS;
 }
 
 int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len, uint32_t *episode,
                       const double *reset_draw, uint64_t seed, uint64_t env_base, const float *params,
-                      int joint, uint64_t sample_step0, float *obs_io, float *states, int *actions,
+                      int joint, int net_mode, uint64_t sample_step0, float *obs_io, float *states, int *actions,
                       float *log_probs, float *values, float *rewards, int *done, int *trunc, float *term_obs,
                       float *ev_dense, float *ret_ring, int *len_ring, int *ring_cnt, int ring, int N, int T, void *stream)
 {
     PPO_REQUIRE(kind == PPO_ENV_CARTPOLE || kind == PPO_ENV_ACROBOT);
+    PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT);
     PPO_REQUIRE(N >= 0 && T >= 0);
     if (N == 0 || T == 0) return 0;
     PPO_REQUIRE(state && elapsed && ep_ret && ep_len && episode && params && obs_io && states && actions &&
                 log_probs && values && rewards && done && trunc && term_obs);
     const size_t oa = kind == PPO_ENV_CARTPOLE ? 16 : 8;
     PPO_REQUIRE(ppo_aligned(state, 16) && ppo_aligned(obs_io, oa) && ppo_aligned(states, oa) &&
-                ppo_aligned(term_obs, oa) && ppo_aligned(params, 4));
+                ppo_aligned(term_obs, oa) && ppo_aligned(params, 16));
     PPO_REQUIRE(!reset_draw || ppo_aligned(reset_draw, 16));
     const bool rings = ret_ring || len_ring || ring_cnt;
     PPO_REQUIRE(!rings || (ret_ring && len_ring && ring_cnt && ring > 0));
@@ -355,8 +602,8 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
     const char *abl = getenv("PPO_ROLLOUT_ABLATE");
     a.ablate = abl ? atoi(abl) : 0;
     hipStream_t s = (hipStream_t)stream;
-    if (kind == PPO_ENV_CARTPOLE) return launch_rollout<CartPole, 2>(a, joint, s);
-    return launch_rollout<Acrobot, 3>(a, joint, s);
+    if (kind == PPO_ENV_CARTPOLE) return launch_rollout<CartPole, 2>(a, joint, net_mode, s);
+    return launch_rollout<Acrobot, 3>(a, joint, net_mode, s);
 }
 
 }  // extern "C"

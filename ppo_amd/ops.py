@@ -286,12 +286,63 @@ def _mfma_frags(weight: torch.Tensor, bias: torch.Tensor, chained: bool = False)
     return frag.reshape(-1)
 
 
-def pack_dense_agent(agent) -> torch.Tensor:
+NET_F32, NET_F16_SPLIT = 0, 1      # include/ppo_amd.h: PPO_NET_F32, PPO_NET_F16_SPLIT
+_TANH_SCALE = 2.0 * 1.4426950408889634   # 2 log2(e): tanh(x) = 1 - 2 / (exp2(_TANH_SCALE x) + 1)
+
+
+def _split_f16(x64: torch.Tensor):
+    """x (float64) -> (hi, lo) float16 with x ~= hi + lo / 2048 to 22 bits (rollout.hip, mode 1)."""
+    hi = x64.to(torch.float16)
+    lo = ((x64 - hi.to(torch.float64)) * 2048.0).to(torch.float16)
+    return hi, lo
+
+
+def _f16_words(t16: torch.Tensor) -> torch.Tensor:
+    """[..., 8] float16 -> [..., 4] float32 holding the same bits (two f16 per 32-bit word)."""
+    return t16.contiguous().view(torch.float32)
+
+
+def _backbone_f16_split(seq) -> list:
+    """One backbone in the mode-1 layout: W1[op][piece][lane][4], W2[j][op][piece][lane][4],
+    B2[op][r][lane]; weights and biases pre-multiplied by 2 log2(e) in float64 before the split."""
+    W1 = seq[0].weight.detach().to(torch.float64) * _TANH_SCALE      # [64, OBS]
+    b1 = seq[0].bias.detach().to(torch.float64) * _TANH_SCALE
+    W2 = seq[2].weight.detach().to(torch.float64) * _TANH_SCALE      # [64, 64]
+    b2 = seq[2].bias.detach().to(torch.float64) * _TANH_SCALE
+    dev = W1.device
+    obs = W1.shape[1]
+    assert obs < 8
+    lane = torch.arange(64, device=dev)
+    half, l31 = lane >> 5, lane & 31
+    # layer 1: k = i for both lane halves; the bias rides on input slot i = obs (the kernel feeds 1.0 there)
+    a1 = W1.new_zeros(2, 64, 8)
+    for op in range(2):
+        a1[op, :, :obs] = W1[32 * op + l31]
+        a1[op, :, obs] = b1[32 * op + l31]
+    h1, l1 = _split_f16(a1)
+    w1 = torch.stack([_f16_words(h1), _f16_words(l1)], dim=1)        # [op, piece, lane, 4]
+    # layer 2: k-step j = 2 o_in + (r_in >> 3), element i = r_in & 7 -> unit(o_in, r_in, half)
+    j = torch.arange(4, device=dev)[:, None, None]
+    i = torch.arange(8, device=dev)[None, None, :]
+    unit = _d_layout_unit(j >> 1, 8 * (j & 1) + i, half[None, :, None])          # [4, 64, 8]
+    a2 = torch.stack([W2[(32 * op + l31)[None, :, None], unit] for op in range(2)], dim=1)   # [j, op, lane, 8]
+    h2, l2 = _split_f16(a2)
+    w2 = torch.stack([_f16_words(h2), _f16_words(l2)], dim=2)        # [j, op, piece, lane, 4]
+    o = torch.arange(2, device=dev)[:, None, None]
+    r = torch.arange(16, device=dev)[None, :, None]
+    bb = b2[_d_layout_unit(o, r, half[None, None, :])].to(torch.float32)         # [op, r, lane]
+    return [w1.reshape(-1), w2.reshape(-1), bb.reshape(-1)]
+
+
+def pack_dense_agent(agent, net_mode: int = NET_F32) -> torch.Tensor:
     """Flatten a dense Agent's parameters into the layout k_rollout reads (rollout.hip): per
-    backbone the MFMA fragments of both tanh layers (the second in register-chained k order), then
-    the per-lane head weights HL[4][2][16][64] (j = 0..2 logits zero padded, j = 3 critic) and
-    bias4 = (policy bias zero padded to 3, critic bias)."""
+    backbone the MFMA fragments of both tanh layers -- f32 fragments, the second layer in
+    register-chained k order (NET_F32), or two-piece f16 splits of the 2 log2(e)-scaled weights
+    (NET_F16_SPLIT) -- then the per-lane head weights HL[4][2][16][64] (j = 0..2 logits zero padded,
+    j = 3 critic) and bias4 = (policy bias zero padded to 3, critic bias)."""
     def backbone(seq):
+        if net_mode == NET_F16_SPLIT:
+            return _backbone_f16_split(seq)
         return [_mfma_frags(seq[0].weight, seq[0].bias), _mfma_frags(seq[2].weight, seq[2].bias, chained=True)]
     with torch.no_grad():
         parts = backbone(agent.pi_backbone)
@@ -316,15 +367,15 @@ def pack_dense_agent(agent) -> torch.Tensor:
 
 
 def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, log_probs, values, rewards, done,
-                  trunc, term_obs, ev_dense, T):
+                  trunc, term_obs, ev_dense, T, net_mode: int = NET_F32):
     """ppo_rollout_fused over a ppo_amd.envs.DeviceEnvBatch; every tensor is written in place."""
     lib = _lib.load()
-    need = lib.ppo_rollout_param_floats(batch.kind, int(bool(joint)))
+    need = lib.ppo_rollout_param_floats(batch.kind, int(bool(joint)), int(net_mode))
     assert params.numel() == need and params.dtype == torch.float32 and params.is_cuda, (params.numel(), need)
     rc = lib.ppo_rollout_fused(
         batch.kind, batch.state.data_ptr(), batch.elapsed.data_ptr(), batch.ep_ret.data_ptr(),
         batch.ep_len.data_ptr(), batch.episode.data_ptr(), None, batch.seed, batch.env_base, params.data_ptr(),
-        int(bool(joint)), int(sample_step0), obs_io.data_ptr(), states.data_ptr(), actions.data_ptr(),
+        int(bool(joint)), int(net_mode), int(sample_step0), obs_io.data_ptr(), states.data_ptr(), actions.data_ptr(),
         log_probs.data_ptr(), values.data_ptr(), rewards.data_ptr(), done.data_ptr(), trunc.data_ptr(),
         term_obs.data_ptr(), _ptr(ev_dense), batch.ret_ring.data_ptr(), batch.len_ring.data_ptr(), batch.ring_cnt.data_ptr(),
         batch.ring, batch.num_envs, int(T), _stream())

@@ -190,6 +190,10 @@ class SyncVecEnv:
         # device path, dense net + Discrete head: the whole T-step rollout (policy forward, sampling,
         # env transition) in ONE kernel launch.  False = PyTorch MLP + one env kernel per time step.
         self.fused_rollout = True
+        # how the whole-rollout kernel multiplies inside the network (include/ppo_amd.h): exact f32
+        # MFMA products (ops.NET_F32), or f16 MFMAs on two-piece splits (ops.NET_F16_SPLIT, ~1.5x faster,
+        # 22 bits per operand); PPO_AMD_NET=f32 selects the former
+        self.net_mode = ops.NET_F32 if os.environ.get("PPO_AMD_NET", "f16_split") == "f32" else ops.NET_F16_SPLIT
         self._rollouts = 0
 
         first = env_fn()
@@ -291,7 +295,8 @@ class SyncVecEnv:
             carry.copy_(self.t_states)
             ops.rollout_fused(b, self._packed_params(), self.agent.joint_net, self._rollouts * T, carry,
                               self.states, self.actions, self.log_probs, self.values, self.rewards,
-                              self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T)
+                              self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T,
+                              net_mode=self.net_mode)
             self._ev_ready = True                      # bootstrap values already written by the kernel
         for t in range(0 if whole else T):
             obs = self.states[t] if same else self.states[t].to(adev)
@@ -322,9 +327,9 @@ class SyncVecEnv:
     def _packed_params(self) -> torch.Tensor:
         """Network in the whole-rollout kernel's layout; repacked only when a parameter changed
         (torch bumps a tensor's _version on every in-place update, i.e. on every optimiser step)."""
-        key = tuple((id(p), p._version) for p in self.agent.parameters())
+        key = (self.net_mode,) + tuple((id(p), p._version) for p in self.agent.parameters())
         if self._packed[0] != key:
-            self._packed = (key, ops.pack_dense_agent(self.agent))
+            self._packed = (key, ops.pack_dense_agent(self.agent, self.net_mode))
         return self._packed[1]
 
     def _locate_end_states(self):

@@ -53,7 +53,8 @@ def test_vec_env_rollout(device):
     assert vec_env.global_steps == 250 and vec_env.total_return == np.float32(250.0)
 
 
-@pytest.mark.parametrize("whole", [False, True], ids=["per_step_kernels", "whole_rollout_kernel"])
+@pytest.mark.parametrize("whole", [None, "f32", "f16_split"],
+                         ids=["per_step_kernels", "whole_rollout_f32", "whole_rollout_f16_split"])
 @pytest.mark.parametrize("joint", [1, 0], ids=["joint", "split"])
 @pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
 def test_device_rollout_matches_serial_reference_loop(kind, joint, whole):
@@ -71,7 +72,9 @@ def test_device_rollout_matches_serial_reference_loop(kind, joint, whole):
         agent.policy.bias.uniform_(-0.5, 0.5)
         agent.critic.bias.fill_(0.3)
     ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=seed), N, T, 0, 0.0, agent, seed=seed)
-    ve.fused_rollout = whole
+    from ppo_amd import ops
+    ve.fused_rollout = whole is not None
+    ve.net_mode = ops.NET_F32 if whole == "f32" else ops.NET_F16_SPLIT
 
     ora = cref.BatchEnv(kind, N, seed=seed)
     t_states = torch.from_numpy(ora.reset())
