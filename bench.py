@@ -126,7 +126,7 @@ def main():
                 _lib.check(lib.ppo_prof_arm(slot), "ppo_prof_arm")
             adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95)
             if record:
-                gae_events.append((slot, (ve.trunc_flags != 0).sum()))
+                gae_events.append(slot)
         return adv
 
     def barrier():
@@ -135,8 +135,9 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        hot_path_step(False)
+        hot_path_step(True)        # same code path as the timed steps, so one-time costs land here
     barrier()
+    gae_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         hot_path_step(True)
@@ -149,11 +150,11 @@ def main():
 
     us = C.c_float()
     gae_us = []
-    for slot, _ in gae_events:
+    for slot in gae_events:
         _lib.check(lib.ppo_prof_elapsed_us(slot, C.byref(us)), "ppo_prof_elapsed_us")
         gae_us.append(us.value)
     gae_ms = float(np.mean(gae_us)) * 1e-3
-    n_trunc = float(np.mean([int(n) for _, n in gae_events]))
+    n_trunc = float((ve.trunc_flags != 0).sum())   # truncated cells of the last rollout (4 B of end value each)
     gae_bytes = int(GAE_BYTES_PER_ELEM * T * N + 4 * n_trunc)
     achieved = gae_bytes / (gae_ms * 1e-3) / 1e9
     traffic = None
