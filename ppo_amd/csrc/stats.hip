@@ -23,7 +23,8 @@ constexpr int SEL_T = 9;          // targets: returns lo/hi of p5, p50, p95; ret
 constexpr int SEL_T_RET = 7;      // targets 0..6 select from the returns, 7..8 from the lengths
 constexpr int SEL_B0 = 4096;      // level-0 buckets (top 12 key bits)
 constexpr int SEL_B1 = 1024;      // level-1 / level-2 buckets (10 bits each)
-constexpr int SEL_BLOCK = 256;
+constexpr int SEL_BLOCK = 256;       // scan kernels
+constexpr int SEL_HBLOCK = 1024;     // histogram kernels: 16 waves share one LDS histogram, 2 blocks fill a CU
 
 struct SelState {                 // lives at the head of the workspace
     unsigned long long n;         // number of valid ring entries (same for returns and lengths)
@@ -67,14 +68,14 @@ __device__ __forceinline__ float key2f(uint32_t k)
 }
 
 template <int LEVEL>
-__global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist(const float *ret_ring, const int *len_ring, const int *ring_cnt,
+__global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, const int *len_ring, const int *ring_cnt,
                                                         int ring, int N, SelWs w)
 {
     constexpr int NH = LEVEL == 0 ? 2 : SEL_T, NB = LEVEL == 0 ? SEL_B0 : SEL_B1;
     constexpr int SHIFT = LEVEL == 0 ? 20 : (LEVEL == 1 ? 10 : 0);     // digit position
     constexpr int PSHIFT = LEVEL == 1 ? 20 : 10;                       // bits below the fixed prefix
     __shared__ uint32_t h[NH * NB];
-    for (int k = threadIdx.x; k < NH * NB; k += SEL_BLOCK) h[k] = 0u;
+    for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK) h[k] = 0u;
     uint32_t prefix[SEL_T];
     bool lead[SEL_T];
     if (LEVEL > 0) {
@@ -83,26 +84,30 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist(const float *ret_ring, c
         for (int t = 0; t < SEL_T; ++t) { prefix[t] = w.st->prefix[t]; lead[t] = w.st->leader[t] != 0; }
     }
     __syncthreads();
-    const size_t total = (size_t)N * ring;
-    for (size_t i = (size_t)blockIdx.x * SEL_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * SEL_BLOCK) {
-        const int n = (int)(i / ring), k = (int)(i % ring);
-        const int c = ring_cnt[n];
-        if (k >= (c < ring ? c : ring)) continue;
-        const uint32_t kr = f2key(ret_ring[i]), kl = f2key((float)len_ring[i]);
-        if (LEVEL == 0) {
-            atomicAdd(&h[kr >> SHIFT], 1u);
-            atomicAdd(&h[SEL_B0 + (kl >> SHIFT)], 1u);
-        } else {
+    // one ring (env) per wave at a time, lanes across its slots: coalesced, and no per-element
+    // division by the run-time ring length
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (SEL_HBLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (SEL_HBLOCK / 64);
+    for (int n = wave; n < N; n += nwaves) {
+        const int c0 = ring_cnt[n], c = c0 < ring ? c0 : ring;
+        const size_t row = (size_t)n * ring;
+        for (int k = lane; k < c; k += 64) {
+            const uint32_t kr = f2key(ret_ring[row + k]), kl = f2key((float)len_ring[row + k]);
+            if (LEVEL == 0) {
+                atomicAdd(&h[kr >> SHIFT], 1u);
+                atomicAdd(&h[SEL_B0 + (kl >> SHIFT)], 1u);
+            } else {
 #pragma unroll
-            for (int t = 0; t < SEL_T; ++t) {
-                const uint32_t key = t < SEL_T_RET ? kr : kl;
-                if (lead[t] && (key >> PSHIFT) == prefix[t]) atomicAdd(&h[t * NB + ((key >> SHIFT) & (NB - 1))], 1u);
+                for (int t = 0; t < SEL_T; ++t) {
+                    const uint32_t key = t < SEL_T_RET ? kr : kl;
+                    if (lead[t] && (key >> PSHIFT) == prefix[t]) atomicAdd(&h[t * NB + ((key >> SHIFT) & (NB - 1))], 1u);
+                }
             }
         }
     }
     __syncthreads();
     uint32_t *g = LEVEL == 0 ? w.hist0 : (LEVEL == 1 ? w.hist1 : w.hist2);
-    for (int k = threadIdx.x; k < NH * NB; k += SEL_BLOCK) {
+    for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK) {
         const uint32_t v = h[k];
         if (v) atomicAdd(&g[k], v);       // integer adds: order-independent, deterministic
     }
@@ -242,7 +247,7 @@ template <int LEVEL>
 int sel_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N, const SelWs &w,
               double *stats5, unsigned blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sel_hist<LEVEL>, dim3(blocks), dim3(SEL_BLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w);
+    hipLaunchKernelGGL(k_sel_hist<LEVEL>, dim3(blocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w);
     int rc = ppo_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(k_sel_scan<LEVEL>, dim3(1), dim3(SEL_BLOCK), 0, s, w, stats5);
@@ -267,9 +272,8 @@ int ppo_episode_stats(const float *ret_ring, const int *len_ring, const int *rin
     hipError_t e = hipMemsetAsync(workspace, 0, SEL_WS_BYTES, s);
     if (e != hipSuccess) return (int)e;
     const SelWs w = sel_ws(workspace);
-    const size_t total = (size_t)N * ring;
-    size_t blocks = (total + SEL_BLOCK * 8 - 1) / (SEL_BLOCK * 8);
-    if (blocks > 1024) blocks = 1024;
+    size_t blocks = ((size_t)N + (SEL_HBLOCK / 64) * 4 - 1) / ((SEL_HBLOCK / 64) * 4);   // >= 4 rings per wave
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     int rc = sel_level<0>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
     if (rc) return rc;
