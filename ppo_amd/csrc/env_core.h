@@ -95,25 +95,33 @@ struct CartPole {
 struct Acrobot {
     static constexpr int OBS = 6;
 
-    __device__ static void write_obs(const double (&s)[4], float (&obs)[6])
+    // sin and cos of one angle share their argument reduction (sincos returns the same values as the
+    // separate calls); 15 reductions per step instead of 22 -- trigonometry is ~70 % of this env.
+    __device__ static void write_obs(const double (&s)[4], float (&obs)[6], double &cos_s0)
     {
-        obs[0] = (float)cos(s[0]); obs[1] = (float)sin(s[0]);
-        obs[2] = (float)cos(s[1]); obs[3] = (float)sin(s[1]);
+        double s0, c0, s1, c1;
+        sincos(s[0], &s0, &c0);
+        sincos(s[1], &s1, &c1);
+        obs[0] = (float)c0; obs[1] = (float)s0;
+        obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
+        cos_s0 = c0;
     }
 
     __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6])
     {
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] = (double)(float)(-0.1 + (0.1 - -0.1) * u[k]);  // .astype(float32)
-        write_obs(s, obs);
+        double unused;
+        write_obs(s, obs, unused);
     }
 
     __device__ static void dsdt(const double (&y)[4], double a, double (&out)[4])
     {
         const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
         const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
-        const double c2 = cos(theta2), s2 = sin(theta2);
+        double c2, s2;
+        sincos(theta2, &s2, &c2);
         const double d1 = m1 * (lc1 * lc1) + m2 * ((l1 * l1) + (lc2 * lc2) + 2 * l1 * lc2 * c2) + I1 + I2;
         const double d2 = m2 * ((lc2 * lc2) + l1 * lc2 * c2) + I2;
         const double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - PI / 2.0);
@@ -160,9 +168,10 @@ struct Acrobot {
         ns[3] = fmin(fmax(ns[3], -9 * PI), 9 * PI);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = ns[i];
-        const bool terminated = (-cos(ns[0]) - cos(ns[1] + ns[0]) > 1.0);
+        double cos_ns0;
+        write_obs(s, obs, cos_ns0);
+        const bool terminated = (-cos_ns0 - cos(ns[1] + ns[0]) > 1.0);
         reward = terminated ? 0.0f : -1.0f;
-        write_obs(s, obs);
         return terminated;
     }
 };
