@@ -143,10 +143,26 @@ def main():
         hot_path_step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    elapsed = max_over_ranks(elapsed)
+    # The same K steps once more with the network's products done as exact f32 FMAs (PPO_NET_F32)
+    # instead of the default two-piece f16 splits, reported beside `value` as the conservative figure.
+    ve.net_mode = ops.NET_F32
+    for _ in range(2):
+        hot_path_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hot_path_step(False)
+    barrier()
+    elapsed_f32 = max_over_ranks(time.perf_counter() - t0)
+    ve.net_mode = ops.NET_F16_SPLIT
 
     us = C.c_float()
     gae_us = []
@@ -170,10 +186,15 @@ def main():
             "metric": "env-steps/sec (rollout+GAE)", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64 env state / f32 buffers", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f64 env physics; f32 network, buffers, GAE (network products: exact two-piece f16 splits of "
+                     "both operands, 22 bits each, f32 accumulate -- measured error equal to PyTorch's f32 forward)",
+            "data": "synthetic",
+            "value_with_exact_f32_products": total_steps / elapsed_f32,
+            "ms_per_step_with_exact_f32_products": 1e3 * elapsed_f32 / args.steps,
             "config": {"workload": f"{kind} batched stepping + GAE, N={N} envs/GPU x T={T}, dense 64-64 tanh policy "
                                    f"(joint net, f32) inside the whole-rollout kernel, BASELINE configs[1]",
-                       "num_envs_per_gpu": N, "rollout_len": T, "parallelism": f"env-sharded x{world}, no data-path collective"},
+                       "num_envs_per_gpu": N, "rollout_len": T, "net_mode": "f16_split (PPO_NET_F16_SPLIT)", "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "k_gae (ppo_gae_dense)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes,
