@@ -24,4 +24,4 @@ for B in (8192, 1 << 20, 1 << 23):
         ops.loss_logits_fwd_bwd(logits, act, old_lp, new_v, old_v, adv, 0.2, 1, 1)
     torch.cuda.synchronize()
     print(f"B={B}: {3 * sets} launches each of ppo_adv_stats + ppo_loss_fwd_bwd (28 B/sample + 4 B stats pass) and "
-          f"ppo_loss_logits_fwd_bwd A=2 (32 B read + 20 B written per sample)")
+          f"ppo_loss_logits_fwd_bwd A=2 (28 B read + 20 B written per sample)")
