@@ -13,8 +13,8 @@
 // key arrays and radix-sorted them (rocPRIM via torch.sort): ~460 us of kernel time per rollout,
 // against ~60 us here.
 //   k_sel_hist<L>  : rings -> LDS histograms -> global histogram(s) of level L
-//   k_sel_scan<L>  : histogram(s) -> bucket and residual rank of every target; the last level
-//                    writes {running max, p5, p50, p95, median length} (f64)
+//   k_sel_scan<L>  : histogram(s) -> bucket and residual rank of every target (one wave per target,
+//                    shuffle scans); the last level writes {running max, p5, p50, p95, median length}
 #include "common.h"
 
 namespace {
@@ -23,7 +23,6 @@ constexpr int SEL_T = 9;          // targets: returns lo/hi of p5, p50, p95; ret
 constexpr int SEL_T_RET = 7;      // targets 0..6 select from the returns, 7..8 from the lengths
 constexpr int SEL_B0 = 4096;      // level-0 buckets (top 12 key bits)
 constexpr int SEL_B1 = 1024;      // level-1 / level-2 buckets (10 bits each)
-constexpr int SEL_BLOCK = 256;       // scan kernels
 constexpr int SEL_HBLOCK = 1024;     // histogram kernels: 16 waves share one LDS histogram, 2 blocks fill a CU
 
 struct SelState {                 // lives at the head of the workspace
@@ -113,41 +112,6 @@ __global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, 
     }
 }
 
-// Inclusive scan of nb (<= 4096, multiple of SEL_BLOCK) bins into cum[] (LDS); returns the total.
-__device__ unsigned long long block_scan_bins(const uint32_t *bins, int nb, unsigned long long *cum,
-                                              unsigned long long *part)
-{
-    const int per = nb / SEL_BLOCK, base = threadIdx.x * per;
-    unsigned long long s = 0;
-    for (int k = 0; k < per; ++k) s += bins[base + k];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < SEL_BLOCK; off <<= 1) {     // Hillis-Steele over the 256 partial sums
-        const unsigned long long add = threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    unsigned long long run = threadIdx.x ? part[threadIdx.x - 1] : 0ull;
-    for (int k = 0; k < per; ++k) {
-        run += bins[base + k];
-        cum[base + k] = run;
-    }
-    __syncthreads();
-    return part[SEL_BLOCK - 1];
-}
-
-// smallest b with cum[b] > rank
-__device__ int find_bucket(const unsigned long long *cum, int nb, unsigned long long rank)
-{
-    int lo = 0, hi = nb - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (cum[mid] > rank) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-
 __device__ void rank_pair(unsigned long long n, double q, unsigned long long &lo, unsigned long long &hi)
 {
     const double pos = q * (double)(n - 1);                 // np.percentile, method "linear"
@@ -161,80 +125,103 @@ __device__ double lerp_pair(double a, double b, unsigned long long n, double q)
     return a + (b - a) * (pos - floor(pos));
 }
 
+// One wave owns one target: lane l holds PER consecutive bins, a shuffle scan gives every lane the
+// count before its bins, and the lane whose bins contain the wanted rank walks them.  No LDS, no
+// block barrier: the nine targets are narrowed concurrently by nine waves.
+template <int PER> struct WaveBins {
+    uint32_t v[PER];
+    unsigned long long excl, incl, total;
+    __device__ __forceinline__ void load(const uint32_t *bins)
+    {
+        const int lane = threadIdx.x & 63;
+        const uint4 *p = reinterpret_cast<const uint4 *>(bins + lane * PER);
+        unsigned long long s = 0;
+#pragma unroll
+        for (int k = 0; k < PER / 4; ++k) {
+            const uint4 x = p[k];
+            v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w;
+            s += (unsigned long long)x.x + x.y + x.z + x.w;
+        }
+        incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        excl = incl - s;
+        total = __shfl(incl, 63, 64);
+    }
+    // bucket holding `rank` (rank < total); rank becomes the residual rank inside that bucket
+    __device__ __forceinline__ int find(unsigned long long &rank) const
+    {
+        const int lane = threadIdx.x & 63;
+        const bool here = rank >= excl && rank < incl;
+        int b = 0;
+        unsigned long long resid = 0;
+        if (here) {
+            unsigned long long run = excl;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                if (rank >= run && rank < run + v[k]) { b = lane * PER + k; resid = rank - run; }
+                run += v[k];
+            }
+        }
+        const int src = __ffsll((long long)__ballot(here)) - 1;
+        rank = __shfl(resid, src, 64);
+        return __shfl(b, src, 64);
+    }
+};
+
+constexpr int SEL_SBLOCK = 64 * SEL_T;   // scan kernels: one wave per target
+
 // stats5 = {running max, p5, p50, p95, median length}; entries keep their previous value (NaN at
 // start) while no episode has finished, like the reference's attributes (src/ppo.py:250-254, :408-417).
-template <int LEVEL> __global__ void __launch_bounds__(SEL_BLOCK) k_sel_scan(SelWs w, double *stats5)
+template <int LEVEL> __global__ void __launch_bounds__(SEL_SBLOCK) k_sel_scan(SelWs w, double *stats5)
 {
-    __shared__ unsigned long long cum[SEL_B0];
-    __shared__ unsigned long long part[SEL_BLOCK];
-    __shared__ unsigned long long s_rank[SEL_T];            // the block works on an LDS copy of the state
+    __shared__ unsigned long long s_rank[SEL_T];
     __shared__ uint32_t s_prefix[SEL_T];
-    __shared__ int s_slot[SEL_T], s_leader[SEL_T];
     SelState *st = w.st;
-    const int tid = threadIdx.x;
-    unsigned long long n;
+    const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;   // this wave's target
+    unsigned long long n, rank;
+    uint32_t prefix;
     if (LEVEL == 0) {
-        n = block_scan_bins(w.hist0, SEL_B0, cum, part);
-        if (n == 0) {                                        // uniform: nothing finished yet
-            if (tid == 0) st->n = 0;
+        WaveBins<SEL_B0 / 64> wb;
+        wb.load(w.hist0 + (t < SEL_T_RET ? 0 : SEL_B0));
+        n = wb.total;                                            // same for returns and lengths
+        if (n == 0) {                                            // uniform: nothing finished yet
+            if (threadIdx.x == 0) st->n = 0;
             return;
         }
-        if (tid == 0) {
-            rank_pair(n, 0.05, s_rank[0], s_rank[1]);
-            rank_pair(n, 0.50, s_rank[2], s_rank[3]);
-            rank_pair(n, 0.95, s_rank[4], s_rank[5]);
-            s_rank[6] = n - 1;
-            rank_pair(n, 0.50, s_rank[7], s_rank[8]);
-        }
-        __syncthreads();
-        if (tid < SEL_T_RET) {
-            const int b = find_bucket(cum, SEL_B0, s_rank[tid]);
-            s_rank[tid] -= b ? cum[b - 1] : 0ull;
-            s_prefix[tid] = (uint32_t)b;
-        }
-        __syncthreads();
-        block_scan_bins(w.hist0 + SEL_B0, SEL_B0, cum, part);
-        if (tid >= SEL_T_RET && tid < SEL_T) {
-            const int b = find_bucket(cum, SEL_B0, s_rank[tid]);
-            s_rank[tid] -= b ? cum[b - 1] : 0ull;
-            s_prefix[tid] = (uint32_t)b;
-        }
+        unsigned long long lo, hi;
+        rank_pair(n, t < 2 ? 0.05 : (t < 4 || t >= SEL_T_RET ? 0.50 : 0.95), lo, hi);
+        const bool upper = t < 6 ? (t & 1) : (t == 8);           // targets come in (lower, upper) pairs
+        rank = t == 6 ? n - 1 : (upper ? hi : lo);
+        prefix = (uint32_t)wb.find(rank);
     } else {
         n = st->n;
         if (n == 0) return;
-        if (tid < SEL_T) {
-            s_rank[tid] = st->rank[tid]; s_prefix[tid] = st->prefix[tid];
-            s_slot[tid] = st->slot[tid]; s_leader[tid] = st->leader[tid];
-        }
-        __syncthreads();
-        const uint32_t *hist = LEVEL == 1 ? w.hist1 : w.hist2;
-        for (int t = 0; t < SEL_T; ++t) {                    // one 1024-bin scan per distinct prefix
-            if (!s_leader[t]) continue;                      // uniform across the block
-            block_scan_bins(hist + t * SEL_B1, SEL_B1, cum, part);
-            if (tid < SEL_T && s_slot[tid] == t) {
-                const int b = find_bucket(cum, SEL_B1, s_rank[tid]);
-                s_rank[tid] -= b ? cum[b - 1] : 0ull;
-                s_prefix[tid] = (s_prefix[tid] << 10) | (uint32_t)b;
-            }
-            __syncthreads();
-        }
+        WaveBins<SEL_B1 / 64> wb;
+        wb.load((LEVEL == 1 ? w.hist1 : w.hist2) + st->slot[t] * SEL_B1);
+        rank = st->rank[t];
+        prefix = (st->prefix[t] << 10) | (uint32_t)wb.find(rank);
     }
+    if (lane == 0) { s_rank[t] = rank; s_prefix[t] = prefix; }
     __syncthreads();
-    if (tid != 0) return;
+    if (threadIdx.x != 0) return;
     if (LEVEL < 2) {                                         // targets with equal prefixes share a histogram
         st->n = n;
-        for (int t = 0; t < SEL_T; ++t) {
-            int s = t;
-            for (int u = (t < SEL_T_RET ? 0 : SEL_T_RET); u < t; ++u)
-                if (s_prefix[u] == s_prefix[t]) { s = u; break; }
-            st->slot[t] = s;
-            st->leader[t] = s == t;
-            st->rank[t] = s_rank[t];
-            st->prefix[t] = s_prefix[t];
+        for (int u = 0; u < SEL_T; ++u) {
+            int sl = u;
+            for (int q = (u < SEL_T_RET ? 0 : SEL_T_RET); q < u; ++q)
+                if (s_prefix[q] == s_prefix[u]) { sl = q; break; }
+            st->slot[u] = sl;
+            st->leader[u] = sl == u;
+            st->rank[u] = s_rank[u];
+            st->prefix[u] = s_prefix[u];
         }
     } else {
         double v[SEL_T];
-        for (int t = 0; t < SEL_T; ++t) v[t] = (double)key2f(s_prefix[t]);
+        for (int u = 0; u < SEL_T; ++u) v[u] = (double)key2f(s_prefix[u]);
         if (!(stats5[0] >= v[6])) stats5[0] = v[6];          // also replaces the initial NaN
         stats5[1] = lerp_pair(v[0], v[1], n, 0.05);
         stats5[2] = lerp_pair(v[2], v[3], n, 0.50);
@@ -250,7 +237,7 @@ int sel_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, i
     hipLaunchKernelGGL(k_sel_hist<LEVEL>, dim3(blocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w);
     int rc = ppo_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_sel_scan<LEVEL>, dim3(1), dim3(SEL_BLOCK), 0, s, w, stats5);
+    hipLaunchKernelGGL(k_sel_scan<LEVEL>, dim3(1), dim3(SEL_SBLOCK), 0, s, w, stats5);
     return ppo_launch_status();
 }
 
