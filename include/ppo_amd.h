@@ -214,6 +214,8 @@ size_t ppo_rollout_param_floats(int kind, int joint, int net_mode);
  *   ev_dense [T,N] f32 or NULL: the critic's value of the terminal observation, written where
  *   trunc != 0 -- the end_value_dense input of ppo_gae_dense, i.e. what the reference computes
  *   with agent.get_values(end_states) (src/ppo.py:555) and reads where trunc != 0 (:478)
+ *   reward_sum  device f64 or NULL: the sum of all T*N rewards is ADDED to it (the caller zeroes
+ *   it) -- SyncVecEnv.total_return (src/ppo.py:318, :348); per-env f32 sums over time, f64 across envs
  * Env state arguments and rings as in ppo_env_step; row T-1 gets the forced truncation.
  * net_mode: PPO_NET_F32 or PPO_NET_F16_SPLIT; `params` must have been packed for that mode.
  * Values / log-probs agree with the PyTorch f32 forward of the same parameters to ~1e-6 (different
@@ -225,8 +227,8 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
                       uint64_t sample_step0,
                       float *obs_io, float *states, int *actions, float *log_probs, float *values,
                       float *rewards, int *done, int *trunc, float *term_obs, float *ev_dense,
-                      float *ret_ring, int *len_ring, int *ring_cnt, int ring, int N, int T,
-                      void *stream);
+                      double *reward_sum, float *ret_ring, int *len_ring, int *ring_cnt, int ring,
+                      int N, int T, void *stream);
 
 /*
  * Episode statistics from the device rings.  Replaces the tail of SyncVecEnv.rollout

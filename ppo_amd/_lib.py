@@ -32,7 +32,7 @@ SIGNATURES = {
     "ppo_episode_stats": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ppo_rollout_param_floats": (_sz, [_i, _i, _i]),
     "ppo_rollout_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp,
-                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 # tuning hook, deliberately not in the public header
 _PRIVATE = {

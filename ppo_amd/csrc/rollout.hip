@@ -50,6 +50,7 @@ struct RolloutArgs {
     int *done, *trunc;       // [T,N]
     float *term_obs;         // [T,N,OBS], written where a flag is raised
     float *ev_dense;         // [T,N] or NULL: V(terminal obs) written where trunc != 0
+    double *reward_sum;      // or NULL: += sum of all rewards of this rollout (one f64 atomic per wave)
     int T;
     int ablate;              // diagnostic only (PPO_ROLLOUT_ABLATE): 1 skip network, 2 skip physics, 4 skip sampling
 };
@@ -493,6 +494,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     for (int k = 0; k < OBS; ++k) obs[k] = a.obs_io[nn * OBS + k];
 
     const size_t N = (size_t)a.env.N;
+    float rsum = 0.0f;
     // Everything loaded above has arrived before the loop starts, so that no vmcnt wait is needed
     // inside it: there it would also wait for the previous step's stores (vmcnt counts both).
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), other counters untouched
@@ -538,6 +540,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
             a.log_probs[row] = logp;
             a.values[row] = value;
             a.rewards[row] = o.reward;
+            rsum += o.reward;
             a.done[row] = o.done;
             a.trunc[row] = o.trunc;
             if (o.done + o.trunc > 0) store_obs<Env>(a.term_obs, row, o.term);
@@ -563,6 +566,10 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     if (live) {
         store_env(e, a.env, n);
         store_obs<Env>(a.obs_io, n, obs);
+    }
+    if (a.reward_sum) {                            // total_return of the rollout (src/ppo.py:318, :348)
+        const double w = wave_sum(live ? (double)rsum : 0.0);
+        if (lane == 0) atomicAdd(a.reward_sum, w);
     }
 }
 
@@ -604,9 +611,11 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
                       const double *reset_draw, uint64_t seed, uint64_t env_base, const float *params,
                       int joint, int net_mode, uint64_t sample_step0, float *obs_io, float *states, int *actions,
                       float *log_probs, float *values, float *rewards, int *done, int *trunc, float *term_obs,
-                      float *ev_dense, float *ret_ring, int *len_ring, int *ring_cnt, int ring, int N, int T, void *stream)
+                      float *ev_dense, double *reward_sum, float *ret_ring, int *len_ring, int *ring_cnt, int ring,
+                      int N, int T, void *stream)
 {
     PPO_REQUIRE(kind == PPO_ENV_CARTPOLE || kind == PPO_ENV_ACROBOT);
+    PPO_REQUIRE(!reward_sum || ppo_aligned(reward_sum, 8));
     PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT);
     PPO_REQUIRE(N >= 0 && T >= 0);
     if (N == 0 || T == 0) return 0;
@@ -625,7 +634,7 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
     a.env.N = N;
     a.params = params; a.sample_step0 = sample_step0; a.obs_io = obs_io; a.states = states; a.actions = actions;
     a.log_probs = log_probs; a.values = values; a.rewards = rewards; a.done = done; a.trunc = trunc;
-    a.term_obs = term_obs; a.ev_dense = ev_dense; a.T = T;
+    a.term_obs = term_obs; a.ev_dense = ev_dense; a.reward_sum = reward_sum; a.T = T;
     const char *abl = getenv("PPO_ROLLOUT_ABLATE");
     a.ablate = abl ? atoi(abl) : 0;
     hipStream_t s = (hipStream_t)stream;

@@ -367,7 +367,7 @@ def pack_dense_agent(agent, net_mode: int = NET_F32) -> torch.Tensor:
 
 
 def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, log_probs, values, rewards, done,
-                  trunc, term_obs, ev_dense, T, net_mode: int = NET_F32):
+                  trunc, term_obs, ev_dense, T, net_mode: int = NET_F32, reward_sum=None):
     """ppo_rollout_fused over a ppo_amd.envs.DeviceEnvBatch; every tensor is written in place."""
     lib = _lib.load()
     need = lib.ppo_rollout_param_floats(batch.kind, int(bool(joint)), int(net_mode))
@@ -377,6 +377,6 @@ def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, l
         batch.ep_len.data_ptr(), batch.episode.data_ptr(), None, batch.seed, batch.env_base, params.data_ptr(),
         int(bool(joint)), int(net_mode), int(sample_step0), obs_io.data_ptr(), states.data_ptr(), actions.data_ptr(),
         log_probs.data_ptr(), values.data_ptr(), rewards.data_ptr(), done.data_ptr(), trunc.data_ptr(),
-        term_obs.data_ptr(), _ptr(ev_dense), batch.ret_ring.data_ptr(), batch.len_ring.data_ptr(), batch.ring_cnt.data_ptr(),
+        term_obs.data_ptr(), _ptr(ev_dense), _ptr(reward_sum), batch.ret_ring.data_ptr(), batch.len_ring.data_ptr(), batch.ring_cnt.data_ptr(),
         batch.ring, batch.num_envs, int(T), _stream())
     _lib.check(rc, "ppo_rollout_fused")

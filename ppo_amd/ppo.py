@@ -293,10 +293,11 @@ class SyncVecEnv:
             if self._ev_dense is None or self._ev_dense.shape != self.rewards.shape:
                 self._ev_dense = torch.empty_like(self.rewards)
             carry.copy_(self.t_states)
+            rsum = torch.zeros(1, dtype=torch.float64, device=kdev)   # fresh per rollout: read lazily later
             ops.rollout_fused(b, self._packed_params(), self.agent.joint_net, self._rollouts * T, carry,
                               self.states, self.actions, self.log_probs, self.values, self.rewards,
                               self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T,
-                              net_mode=self.net_mode)
+                              net_mode=self.net_mode, reward_sum=rsum)
             self._ev_ready = True                      # bootstrap values already written by the kernel
         for t in range(0 if whole else T):
             obs = self.states[t] if same else self.states[t].to(adev)
@@ -316,7 +317,8 @@ class SyncVecEnv:
         self.global_steps += T * N
         self.t_states = carry if same else carry.to(adev)
         self._end_states = self._end_n = self._end_t = None   # built on first access (end_states property)
-        self._total_return = self.rewards.sum(dtype=torch.float32)   # device scalar, fetched on read
+        # device scalar, fetched on read; the whole-rollout kernel sums the rewards itself
+        self._total_return = rsum[0] if whole else self.rewards.sum(dtype=torch.float32)
         if not same:
             self._locate_end_states()
             for name in ("states", "actions", "rewards", "done_flags", "trunc_flags", "values", "log_probs",

@@ -115,6 +115,7 @@ def test_device_rollout_matches_serial_reference_loop(kind, joint, whole):
         t_states = ref["t_states"]
         assert torch.equal(ve.done_flags.cpu(), ref["done"]) and torch.equal(ve.trunc_flags.cpu(), ref["trunc"])
         assert torch.equal(ve.rewards.cpu(), ref["rewards"])
+        assert float(ve.total_return) == float(ref["rewards"].sum(dtype=torch.float64))   # integer-valued: exact
         assert torch.allclose(ve.states.detach().cpu(), ref["states"], rtol=1e-5, atol=1e-6)
         assert ve.end_states.shape == ref["end_states"].shape
         assert torch.allclose(ve.end_states.cpu(), ref["end_states"], rtol=1e-5, atol=1e-6)
