@@ -175,7 +175,25 @@ template <int VEC, int U> struct EvBlock {
     typename VecT<VEC>::F ev[U];
 };
 
-template <int VEC, int U>
+// NT: non-temporal accesses (every element is touched exactly once)
+template <int BYTES> struct RawT;
+template <> struct RawT<4> { using T = uint32_t; };
+template <> struct RawT<8> { using T = __attribute__((ext_vector_type(2))) uint32_t; };
+template <> struct RawT<16> { using T = __attribute__((ext_vector_type(4))) uint32_t; };
+template <bool NT, class V> __device__ __forceinline__ V ld_stream(const V *p)
+{
+    using R = typename RawT<sizeof(V)>::T;
+    if (NT) return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const R *>(p)));
+    return *p;
+}
+template <bool NT, class V> __device__ __forceinline__ void st_stream(V *p, const V &x)
+{
+    using R = typename RawT<sizeof(V)>::T;
+    if (NT) __builtin_nontemporal_store(__builtin_bit_cast(R, x), reinterpret_cast<R *>(p));
+    else *p = x;
+}
+
+template <int VEC, int U, bool NT = false>
 __device__ __forceinline__ void load_flags(FlagBlock<VEC, U> &b, const GaeArgs &a, size_t col, int t_top)
 {
     using F = typename VecT<VEC>::F;
@@ -183,10 +201,17 @@ __device__ __forceinline__ void load_flags(FlagBlock<VEC, U> &b, const GaeArgs &
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const size_t o = (size_t)(t_top - u) * (size_t)a.N + col;
-        b.r[u] = *reinterpret_cast<const F *>(a.r + o);
-        b.v[u] = *reinterpret_cast<const F *>(a.v + o);
-        b.d[u] = *reinterpret_cast<const I *>(a.done + o);
-        b.tr[u] = *reinterpret_cast<const I *>(a.trunc + o);
+        if constexpr (NT) {
+            b.r[u] = ld_stream<true>(reinterpret_cast<const F *>(a.r + o));
+            b.v[u] = ld_stream<true>(reinterpret_cast<const F *>(a.v + o));
+            b.d[u] = ld_stream<true>(reinterpret_cast<const I *>(a.done + o));
+            b.tr[u] = ld_stream<true>(reinterpret_cast<const I *>(a.trunc + o));
+        } else {
+            b.r[u] = *reinterpret_cast<const F *>(a.r + o);
+            b.v[u] = *reinterpret_cast<const F *>(a.v + o);
+            b.d[u] = *reinterpret_cast<const I *>(a.done + o);
+            b.tr[u] = *reinterpret_cast<const I *>(a.trunc + o);
+        }
     }
 }
 
@@ -211,7 +236,7 @@ __device__ __forceinline__ void load_ev_sparse(EvBlock<VEC, U> &e, const FlagBlo
     }
 }
 
-template <int VEC, int U>
+template <int VEC, int U, bool NT = false>
 __device__ __forceinline__ void consume_sparse(const FlagBlock<VEC, U> &b, const EvBlock<VEC, U> &e, const GaeArgs &a,
                                                size_t col, int t_top, float (&nv)[VEC], float (&na)[VEC])
 {
@@ -229,12 +254,17 @@ __device__ __forceinline__ void consume_sparse(const FlagBlock<VEC, U> &b, const
             fset<VEC>(rout, k, adv + v);
         }
         const size_t o = (size_t)(t_top - u) * (size_t)a.N + col;
-        *reinterpret_cast<F *>(a.adv + o) = out;
-        if (a.ret) *reinterpret_cast<F *>(a.ret + o) = rout;
+        if constexpr (NT) {
+            st_stream<true>(reinterpret_cast<F *>(a.adv + o), out);
+            if (a.ret) st_stream<true>(reinterpret_cast<F *>(a.ret + o), rout);
+        } else {
+            *reinterpret_cast<F *>(a.adv + o) = out;
+            if (a.ret) *reinterpret_cast<F *>(a.ret + o) = rout;
+        }
     }
 }
 
-template <int VEC, int U>
+template <int VEC, int U, bool NT = false>
 __global__ void __launch_bounds__(256) k_gae_sparse(GaeArgs a)
 {
     const size_t col = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
@@ -247,26 +277,26 @@ __global__ void __launch_bounds__(256) k_gae_sparse(GaeArgs a)
     int t = a.T - 1;
     FlagBlock<VEC, U> f0, f1, f2;   // blocks b, b+1, b+2
     EvBlock<VEC, U> e0, e1;         // end values of blocks b, b+1
-    if (nblk > 0) load_flags<VEC, U>(f0, a, col, t);
-    if (nblk > 1) load_flags<VEC, U>(f1, a, col, t - U);
+    if (nblk > 0) load_flags<VEC, U, NT>(f0, a, col, t);
+    if (nblk > 1) load_flags<VEC, U, NT>(f1, a, col, t - U);
     if (nblk > 0) load_ev_sparse<VEC, U>(e0, f0, a, col, t);
     for (int b = 0; b < nblk; ++b) {
-        if (b + 2 < nblk) load_flags<VEC, U>(f2, a, col, t - 2 * U);
+        if (b + 2 < nblk) load_flags<VEC, U, NT>(f2, a, col, t - 2 * U);
         if (b + 1 < nblk) load_ev_sparse<VEC, U>(e1, f1, a, col, t - U);
-        consume_sparse<VEC, U>(f0, e0, a, col, t, nv, na);
+        consume_sparse<VEC, U, NT>(f0, e0, a, col, t, nv, na);
         f0 = f1; f1 = f2; e0 = e1;
         t -= U;
     }
     for (; t >= 0; --t) {
         FlagBlock<VEC, 1> f;
         EvBlock<VEC, 1> e;
-        load_flags<VEC, 1>(f, a, col, t);
+        load_flags<VEC, 1, NT>(f, a, col, t);
         load_ev_sparse<VEC, 1>(e, f, a, col, t);
-        consume_sparse<VEC, 1>(f, e, a, col, t, nv, na);
+        consume_sparse<VEC, 1, NT>(f, e, a, col, t, nv, na);
     }
 }
 
-template <int VEC, int U> int launch_gae_sparse(const GaeArgs &a, hipStream_t s)
+template <int VEC, int U, bool NT = false> int launch_gae_sparse(const GaeArgs &a, hipStream_t s)
 {
     const long threads = a.N / VEC;
     const long waves = (threads + 63) / 64;
@@ -275,11 +305,11 @@ template <int VEC, int U> int launch_gae_sparse(const GaeArgs &a, hipStream_t s)
     if (g_prof_armed >= 0) {
         const int slot = g_prof_armed;
         g_prof_armed = -1;
-        hipExtLaunchKernelGGL((k_gae_sparse<VEC, U>), dim3((unsigned)grid), dim3(block), 0, s, g_prof_start[slot],
+        hipExtLaunchKernelGGL((k_gae_sparse<VEC, U, NT>), dim3((unsigned)grid), dim3(block), 0, s, g_prof_start[slot],
                               g_prof_stop[slot], 0, a);
         return ppo_launch_status();
     }
-    hipLaunchKernelGGL((k_gae_sparse<VEC, U>), dim3((unsigned)grid), dim3(block), 0, s, a);
+    hipLaunchKernelGGL((k_gae_sparse<VEC, U, NT>), dim3((unsigned)grid), dim3(block), 0, s, a);
     return ppo_launch_status();
 }
 
@@ -368,7 +398,9 @@ template <int VEC, int U, bool DENSE_EV> int launch_gae(const GaeArgs &a, hipStr
 }
 
 // Variant table (tools/tune_gae.py; numbers in DESIGN.md).  0-1 stream the dense end-value
-// buffer, 2-5 fetch it only where a truncation is flagged.
+// buffer, 2-7 fetch it only where a truncation is flagged; 6-7 use non-temporal accesses (measured
+// inside bench.py: <2,8> 34.0 us, <2,8,nt> 39.5, <1,8> 35.2, <1,8,nt> 33.5 -- no clear win, and the
+// <2,8> form is sensitive to how the compiler schedules its loads, so its source is left as it is).
 int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s)
 {
     switch (variant) {
@@ -378,11 +410,13 @@ int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s)
     case 3: return launch_gae_sparse<1, 8>(a, s);
     case 4: return launch_gae_sparse<2, 4>(a, s);
     case 5: return launch_gae_sparse<2, 8>(a, s);
+    case 6: return launch_gae_sparse<2, 8, true>(a, s);
+    case 7: return launch_gae_sparse<1, 8, true>(a, s);
     default: return (int)hipErrorInvalidValue;
     }
 }
 
-int variant_vec(int variant) { return (variant == 1 || variant == 4 || variant == 5) ? 2 : 1; }
+int variant_vec(int variant) { return (variant == 1 || variant == 4 || variant == 5 || variant == 6) ? 2 : 1; }
 
 }  // namespace
 

@@ -7,11 +7,14 @@ with no HIP device every op raises.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
 
 _ws_cache: dict = {}
+_GAE_VARIANT = int(os.environ["PPO_GAE_VARIANT"]) if "PPO_GAE_VARIANT" in os.environ else None   # tuning only
 
 
 def device() -> torch.device:
@@ -54,6 +57,8 @@ def gae_dense(rewards, values, end_value_dense, done_flags, trunc_flags, gamma, 
     assert v.shape == (T, N) and ev.shape == (T, N) and d.shape == (T, N) and tr.shape == (T, N)
     adv = out if out is not None else torch.empty((T, N), dtype=torch.float32, device=r.device)
     ret = torch.empty((T, N), dtype=torch.float32, device=r.device) if want_returns else None
+    if variant is None and _GAE_VARIANT is not None:
+        variant = _GAE_VARIANT
     if variant is None:
         rc = lib.ppo_gae_dense(_ptr(r), _ptr(v), _ptr(ev), _ptr(d), _ptr(tr), float(gamma), float(lam),
                                _ptr(adv), _ptr(ret), T, N, _stream())
