@@ -286,8 +286,6 @@ class SyncVecEnv:
         self._alloc(kdev)
         if self._term_obs is None or self._term_obs.shape[0] != T:
             self._term_obs = torch.empty((T, N, b.obs_dim), dtype=torch.float32, device=kdev)
-        carry = torch.empty((N, b.obs_dim), dtype=torch.float32, device=kdev)
-        self.states[0].copy_(self.t_states)
         fused = self.fused_sampling and same and self.agent.discrete
         whole = (self.fused_rollout and same and self.agent.discrete and not self.agent.conv_net
                  and self.agent.action_space.n == ppo_envs.NUM_ACTIONS[b.kind])
@@ -295,13 +293,16 @@ class SyncVecEnv:
         if whole:
             if self._ev_dense is None or self._ev_dense.shape != self.rewards.shape:
                 self._ev_dense = torch.empty_like(self.rewards)
-            carry.copy_(self.t_states)
+            carry = self.t_states.contiguous()         # obs_io: read at t = 0, overwritten with the carried obs
             rsum = torch.zeros(1, dtype=torch.float64, device=kdev)   # fresh per rollout: read lazily later
             ops.rollout_fused(b, self._packed_params(), self.agent.joint_net, self._rollouts * T, carry,
                               self.states, self.actions, self.log_probs, self.values, self.rewards,
                               self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T,
                               net_mode=self.net_mode, reward_sum=rsum)
             self._ev_ready = True                      # bootstrap values already written by the kernel
+        else:
+            carry = torch.empty((N, b.obs_dim), dtype=torch.float32, device=kdev)
+            self.states[0].copy_(self.t_states)
         for t in range(0 if whole else T):
             obs = self.states[t] if same else self.states[t].to(adev)
             if fused:
