@@ -176,6 +176,24 @@ struct Acrobot {
     }
 };
 
+// Streaming variant: non-temporal stores for rollout buffers that nothing on the device reads again
+// soon, so that they do not push the buffers the GAE kernel reads next out of the Infinity Cache.
+template <class Env> __device__ __forceinline__ void store_obs_stream(float *dst, size_t n, const float (&obs)[6])
+{
+    using u4 = __attribute__((ext_vector_type(4))) float;
+    using u2 = __attribute__((ext_vector_type(2))) float;
+    if (Env::OBS == 4) {
+        const u4 v = {obs[0], obs[1], obs[2], obs[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<u4 *>(dst + n * 4));
+    } else {
+        u2 *p = reinterpret_cast<u2 *>(dst + n * 6);
+        const u2 a = {obs[0], obs[1]}, b = {obs[2], obs[3]}, c = {obs[4], obs[5]};
+        __builtin_nontemporal_store(a, p);
+        __builtin_nontemporal_store(b, p + 1);
+        __builtin_nontemporal_store(c, p + 2);
+    }
+}
+
 template <class Env> __device__ __forceinline__ void store_obs(float *dst, size_t n, const float (&obs)[6])
 {
     if (Env::OBS == 4) {

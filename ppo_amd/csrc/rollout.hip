@@ -535,9 +535,11 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
                 for (int k = 0; k < 6; ++k) o.term[k] = o.obs[k];
             }
             const size_t row = (size_t)t * N + n;
-            store_obs<Env>(a.states, row, obs);        // pre-step observation (src/ppo.py:390)
-            a.actions[row] = action;
-            a.log_probs[row] = logp;
+            // states / actions / log-probs are next read by the update phase: stream them past the
+            // caches; rewards, values and flags are what the GAE kernel reads right after this kernel
+            store_obs_stream<Env>(a.states, row, obs);  // pre-step observation (src/ppo.py:390)
+            __builtin_nontemporal_store(action, a.actions + row);
+            __builtin_nontemporal_store(logp, a.log_probs + row);
             a.values[row] = value;
             a.rewards[row] = o.reward;
             rsum += o.reward;
