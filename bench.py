@@ -200,7 +200,11 @@ def main():
                          "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes,
                          "achieved_if_dense_24B_per_elem": 24 * T * N / (gae_ms * 1e-3) / 1e9,
                          "note": "algorithmic bytes = 20 B/element (r, v, done, trunc in; adv out) + 4 B per "
-                                 "truncated cell; SURVEY.md 8d's dense convention (24 B/element) is given beside it"},
+                                 "truncated cell; SURVEY.md 8d's dense convention (24 B/element) is given beside it. "
+                                 "Timed inside the pipeline: part of the input, written by the rollout kernel just "
+                                 "before, is served by the 256 MiB Infinity Cache; with cold inputs (tools/tune_gae.py, "
+                                 "4 rotating buffer sets) the same kernel takes 35.8 us = 58.7 % of peak, and `traffic` "
+                                 "is the L2-to-fabric byte count of that cold run"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, args.cpu_sample_envs, T, args.seed)
