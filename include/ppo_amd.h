@@ -187,6 +187,18 @@ int ppo_minibatch_gather(const int64_t *idx, long B, long M, const void *states,
                          void *stream);
 
 /*
+ * Weight and bias gradient of y = x W^T + b for a small layer (M, K <= 64) over a huge batch:
+ * dW[M,K] = sum_b g[b,m] x[b,k], db[M] = sum_b g[b,m] (db may be NULL).  Replaces the weight-gradient
+ * GEMMs inside loss.backward() of the update phase (src/ppo.py:606-607, :614-615, :623-624) for the
+ * dense network's Linear layers (:126-145); the batch is streamed once, partial sums are added in a
+ * fixed order (deterministic).  g [B,M], x [B,K] f32 row-major; workspace of
+ * ppo_linear_wgrad_workspace_bytes(B) bytes.
+ */
+size_t ppo_linear_wgrad_workspace_bytes(long B);
+int ppo_linear_wgrad(const float *g, const float *x, long B, int M, int K, float *dW, float *db,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Categorical sampling for the rollout's policy step: for each row of logits[N,A]
  * draw an action with Philox4x32-10 keyed (seed; env_base+n, step) and return its
  * log-probability.  Replaces torch.distributions.Categorical(logits).sample() and

@@ -27,6 +27,8 @@ SIGNATURES = {
     "ppo_loss_logits_fwd_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _l, _vp, _vp, _vp, _vp,
                                      _vp, _sz, _vp]),
     "ppo_minibatch_gather": (_i, [_vp, _l, _l, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ppo_linear_wgrad_workspace_bytes": (_sz, [_l]),
+    "ppo_linear_wgrad": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ppo_categorical_sample": (_i, [_vp, _i, _u64, _u64, _u64, _vp, _vp, _i, _vp]),
     "ppo_episode_stats_workspace_bytes": (_sz, []),
     "ppo_episode_stats": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -245,6 +245,49 @@ def minibatch_gather(idx, states, actions, log_probs, values, adv, check_index=F
     return mb_st, mb_act, mb_lp, mb_v, mb_a
 
 
+# --------------------------------------------------------------------------- update-phase Linear
+def linear_wgrad(g: torch.Tensor, x: torch.Tensor, want_bias: bool = True):
+    """(dW [M,K], db [M]) of y = x W^T + b from g = dL/dy [B,M] and x [B,K] (ppo_linear_wgrad)."""
+    lib = _lib.load()
+    g_, x_ = _dev(g, torch.float32), _dev(x, torch.float32)
+    B, M = g_.shape
+    K = x_.shape[1]
+    assert x_.shape[0] == B
+    dW = torch.empty((M, K), dtype=torch.float32, device=g_.device)
+    db = torch.empty(M, dtype=torch.float32, device=g_.device) if want_bias else None
+    ws = _workspace(lib.ppo_linear_wgrad_workspace_bytes(B), g_.device)
+    _lib.check(lib.ppo_linear_wgrad(_ptr(g_), _ptr(x_), B, M, K, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+               "ppo_linear_wgrad")
+    return dW, db
+
+
+class _LinearFn(torch.autograd.Function):
+    """F.linear whose weight / bias gradients come from ppo_linear_wgrad (one streaming pass over the
+    batch) instead of a BLAS GEMM with K = batch size."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        dW, db = linear_wgrad(g, x)
+        return gx, dW, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """y = x W^T + b; large 2-D CUDA batches of small layers back-propagate through ppo_linear_wgrad."""
+    if (x.is_cuda and x.dim() == 2 and x.shape[0] >= 4096 and weight.shape[0] <= 64 and weight.shape[1] <= 64
+            and x.dtype == torch.float32 and bias is not None and torch.is_grad_enabled()
+            and (weight.requires_grad or bias.requires_grad)):
+        return _LinearFn.apply(x.contiguous(), weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 # --------------------------------------------------------------------------- sampling
 def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int, action_out=None, logp_out=None):
     lib = _lib.load()
