@@ -327,64 +327,74 @@ __global__ void __launch_bounds__(256) k_stream_ceiling(const float4 *r, const f
 }
 
 // --- ragged pre-pass: ep_counts (src/ppo.py:468) and cumsum - 1 (:469) ------------
-__global__ void __launch_bounds__(256) k_ep_counts(const int *done, const int *trunc, long *counts, int T, int N)
+// k_ep_counts: one lane per column, eight rows of flags in flight; also the total of each block of
+// 256 columns.  k_scan_apply: every block adds up the totals of the blocks before it and scans its
+// own 256 counts (shuffles + one LDS stage) -- no serial single-workgroup pass.
+constexpr int RAG_BLOCK = 256;
+
+__device__ __forceinline__ long block_sum_256(long x, long *lds4)
 {
-    const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= (size_t)N) return;
-    long c = 0;
-    for (int t = 0; t < T; ++t) {
-        const size_t o = (size_t)t * N + n;
-        const int d = done[o], tr = trunc[o];
-        c += d + tr - d * tr;
-    }
-    counts[n] = c;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, PPO_WAVE);
+    __syncthreads();                       // lds4 may still be read from a previous use
+    if (lane == 0) lds4[wid] = x;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
-// Single-workgroup inclusive scan (N is at most a few 100k columns; the ragged form is
-// the compatibility path).  In place: counts[n] <- cumsum(counts)[n] - 1.
-constexpr int SCAN_THREADS = 1024;
-constexpr int SCAN_PER_THREAD = 16;
-__global__ void __launch_bounds__(SCAN_THREADS) k_cumsum_minus1(long *counts, int N)
+__global__ void __launch_bounds__(RAG_BLOCK) k_ep_counts(const int *done, const int *trunc, long *counts, long *totals,
+                                                         int T, int N)
 {
-    __shared__ long wave_tot[SCAN_THREADS / PPO_WAVE];
-    __shared__ long carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (long base = 0; base < N; base += (long)SCAN_THREADS * SCAN_PER_THREAD) {
-        const long first = base + (long)tid * SCAN_PER_THREAD;
-        long loc[SCAN_PER_THREAD];
-        long sum = 0;
+    __shared__ long lds4[4];
+    const size_t n = (size_t)blockIdx.x * RAG_BLOCK + threadIdx.x;
+    long c = 0;
+    if (n < (size_t)N) {
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {
+            int d[8], tr[8];
 #pragma unroll
-        for (int i = 0; i < SCAN_PER_THREAD; ++i) {
-            const long n = first + i;
-            sum += (n < N) ? counts[n] : 0;
-            loc[i] = sum;
-        }
-        long incl = sum;  // inclusive scan of per-thread sums across the wave
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = (size_t)(t + u) * N + n;
+                d[u] = done[o];
+                tr[u] = trunc[o];
+            }
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const long y = __shfl_up(incl, off, PPO_WAVE);
-            if (lane >= off) incl += y;
+            for (int u = 0; u < 8; ++u) c += d[u] + tr[u] - d[u] * tr[u];
         }
-        if (lane == 63) wave_tot[wid] = incl;
-        __syncthreads();
-        long wave_off = 0, total = 0;
-        for (int w = 0; w < SCAN_THREADS / PPO_WAVE; ++w) {
-            const long wt = wave_tot[w];
-            if (w < wid) wave_off += wt;
-            total += wt;
+        for (; t < T; ++t) {
+            const size_t o = (size_t)t * N + n;
+            const int d = done[o], tr = trunc[o];
+            c += d + tr - d * tr;
         }
-        const long excl = carry_s + wave_off + (incl - sum);
-#pragma unroll
-        for (int i = 0; i < SCAN_PER_THREAD; ++i) {
-            const long n = first + i;
-            if (n < N) counts[n] = excl + loc[i] - 1;
-        }
-        __syncthreads();
-        if (tid == 0) carry_s += total;
-        __syncthreads();
+        counts[n] = c;
     }
+    const long tot = block_sum_256(c, lds4);
+    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+
+// In place: counts[n] <- cumsum(counts)[n] - 1.
+__global__ void __launch_bounds__(RAG_BLOCK) k_scan_apply(long *counts, const long *totals, int N)
+{
+    __shared__ long lds4[4];
+    __shared__ long wave_tot[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    long before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += RAG_BLOCK) before += totals[b];
+    before = block_sum_256(before, lds4);
+    const size_t n = (size_t)blockIdx.x * RAG_BLOCK + threadIdx.x;
+    const long c = n < (size_t)N ? counts[n] : 0;
+    long incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long y = __shfl_up(incl, off, PPO_WAVE);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    long wave_off = 0;
+    for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
+    if (n < (size_t)N) counts[n] = before + wave_off + incl - 1;
 }
 
 template <int VEC, int U, bool DENSE_EV> int launch_gae(const GaeArgs &a, hipStream_t s)
@@ -492,7 +502,10 @@ int ppo_stream_ceiling(const float *r, const float *v, const float *ev, const in
     return ppo_launch_status();
 }
 
-size_t ppo_gae_ragged_workspace_bytes(int N) { return N > 0 ? (size_t)N * sizeof(long) : 0; }
+size_t ppo_gae_ragged_workspace_bytes(int N)
+{
+    return N > 0 ? ((size_t)N + (size_t)((N + RAG_BLOCK - 1) / RAG_BLOCK)) * sizeof(long) : 0;
+}
 
 int ppo_gae_ragged(const float *rewards, const float *values, const float *end_values, long E,
                    const int *done, const int *trunc, double gamma, double lam, float *adv, int T,
@@ -506,10 +519,12 @@ int ppo_gae_ragged(const float *rewards, const float *values, const float *end_v
     PPO_REQUIRE(ppo_aligned(workspace, 8));
     hipStream_t s = (hipStream_t)stream;
     long *idx0 = reinterpret_cast<long *>(workspace);
-    hipLaunchKernelGGL(k_ep_counts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, done, trunc, idx0, T, N);
+    long *totals = idx0 + N;
+    const unsigned nb = (unsigned)((N + RAG_BLOCK - 1) / RAG_BLOCK);
+    hipLaunchKernelGGL(k_ep_counts, dim3(nb), dim3(RAG_BLOCK), 0, s, done, trunc, idx0, totals, T, N);
     int rc = ppo_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cumsum_minus1, dim3(1), dim3(SCAN_THREADS), 0, s, idx0, N);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(RAG_BLOCK), 0, s, idx0, totals, N);
     rc = ppo_launch_status();
     if (rc) return rc;
     GaeArgs a{rewards, values, end_values, done, trunc, adv, nullptr, idx0, E, err_flag,
