@@ -263,29 +263,33 @@ struct Frag16 {
     uint32_t w[4];
 };
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
-constexpr float SPLIT_UP = 2048.0f, SPLIT_DOWN = 1.0f / 2048.0f;
 constexpr int BB16_W1 = 2 * 2 * 64 * 4, BB16_W2 = 4 * 2 * 2 * 64 * 4, BB16_B2 = 2 * 16 * 64;
 constexpr int BB16_WORDS = BB16_W1 + BB16_W2 + BB16_B2;
+#ifndef PPO_JOINT_HL_LDS
+#define PPO_JOINT_HL_LDS true
+#endif
 
 __device__ __forceinline__ f32x16 mfma16(const Frag16 &a, const Frag16 &b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
-// (a0, a1) -> packed f16 pairs of the high pieces and of the scaled low pieces
+// (a0, a1) -> packed f16 pairs of the high pieces (round toward zero) and of the low pieces: the
+// residual a - hi (exact in f32) rounded to f16, one v_fma_mixlo/mixhi_f16 each (src0 is read as
+// the f16 half of `hi`, the other operands as f32).  hipcc does not form these from C (it packs
+// the two residuals into v_pk_fma_f32 and converts separately: 5 instructions instead of 3).
 __device__ __forceinline__ void split2(float a0, float a1, uint32_t &hi, uint32_t &lo)
 {
-    const auto p = __builtin_amdgcn_cvt_pkrtz(a0, a1);
-    const float h0 = (float)p[0], h1 = (float)p[1];
-    const auto q = __builtin_amdgcn_cvt_pkrtz((a0 - h0) * SPLIT_UP, (a1 - h1) * SPLIT_UP);
-    hi = __builtin_bit_cast(uint32_t, p);
-    lo = __builtin_bit_cast(uint32_t, q);
+    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
 }
 
 // tanh of an argument already multiplied by 2 log2(e)
 __device__ __forceinline__ float tanh_prescaled(float x2)
 {
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x2) + 1.0f);
+    // one fma: 2 r is exact, so this is bit-identical to 1 - 2 r and one instruction shorter
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x2) + 1.0f), 1.0f);
 }
 
 struct RegW16 {
@@ -345,8 +349,12 @@ struct RegHL {
     __device__ __forceinline__ float get(int j, int op, int r) const { return v[j][op][r]; }
 };
 struct LdsHL {
-    const float *p;   // LDS copy of HL, already offset by the lane
-    __device__ __forceinline__ float get(int j, int op, int r) const { return p[((j * 2 + op) * 16 + r) * 64]; }
+    const float *p;   // LDS copy of HL as [j][op][r / 4][lane][r % 4], already offset by 4 lane:
+                      // four consecutive r are one conflict-free ds_read_b128
+    __device__ __forceinline__ float get(int j, int op, int r) const
+    {
+        return p[((j * 2 + op) * 4 + (r >> 2)) * 256 + (r & 3)];
+    }
 };
 
 template <int OBS, int A, bool DO_P, bool DO_V, class W, class HLT>
@@ -372,13 +380,13 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
         }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const f32x16 m = mfma16(w.get1(o, 0), bh, zero16());
-            f32x16 c = mfma16(w.get1(o, 1), bh, zero16());
-            c = mfma16(w.get1(o, 0), bl, c);
+            f32x16 m = mfma16(w.get1(o, 1), bh, zero16());    // small cross terms first
+            m = mfma16(w.get1(o, 0), bl, m);
+            m = mfma16(w.get1(o, 0), bh, m);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float a0 = tanh_prescaled(__builtin_fmaf(c[r], SPLIT_DOWN, m[r]));
-                const float a1 = tanh_prescaled(__builtin_fmaf(c[r + 1], SPLIT_DOWN, m[r + 1]));
+                const float a0 = tanh_prescaled(m[r]);
+                const float a1 = tanh_prescaled(m[r + 1]);
                 split2(a0, a1, b2h[e][2 * o + (r >> 3)].w[(r & 7) >> 1], b2l[e][2 * o + (r >> 3)].w[(r & 7) >> 1]);
             }
         }
@@ -388,26 +396,32 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j][0] = p[j][1] = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < 2; ++e) {
+        // the two output tiles' accumulator chains interleave: each MFMA depends on the one before last
+        f32x16 m[2] = {w.bias2(0), w.bias2(1)};
 #pragma unroll
-        for (int op = 0; op < 2; ++op) {
-            f32x16 m = w.bias2(op), c = zero16();
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                m = mfma16(w.get2(j, op, 0), b2h[e][j], m);
-                c = mfma16(w.get2(j, op, 1), b2h[e][j], c);
-                c = mfma16(w.get2(j, op, 0), b2l[e][j], c);
-            }
+            for (int op = 0; op < 2; ++op) m[op] = mfma16(w.get2(j, op, 1), b2h[e][j], m[op]);
+#pragma unroll
+            for (int op = 0; op < 2; ++op) m[op] = mfma16(w.get2(j, op, 0), b2l[e][j], m[op]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int op = 0; op < 2; ++op) m[op] = mfma16(w.get2(j, op, 0), b2h[e][j], m[op]);
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float h = tanh_prescaled(__builtin_fmaf(c[r], SPLIT_DOWN, m[r]));
+                const float h = tanh_prescaled(m[op][r]);
                 if (DO_P) {
 #pragma unroll
                     for (int j = 0; j < A; ++j) p[j][e] = __builtin_fmaf(h, hl.get(j, op, r), p[j][e]);
                 }
                 if (DO_V) p[3][e] = __builtin_fmaf(h, hl.get(3, op, r), p[3][e]);
             }
-        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if ((j < A && DO_P) || (j == 3 && DO_V)) {
@@ -439,12 +453,15 @@ template <int OBS_, int A_, bool JOINT_, bool HL_LDS_> struct NetF16 {
             for (int k = threadIdx.x; k < BB16_WORDS; k += ROLLOUT_BLOCK) smem[k] = params[BB16_WORDS + k];
         }
         if (HL_LDS) {
-            for (int k = threadIdx.x; k < HL_WORDS; k += ROLLOUT_BLOCK) shl[k] = heads[k];
+            for (int k = threadIdx.x; k < HL_WORDS; k += ROLLOUT_BLOCK) {     // k = (jo * 16 + r) * 64 + lane
+                const int l = k & 63, r = (k >> 6) & 15, jo = k >> 10;
+                shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = heads[k];
+            }
         }
         if (!JOINT || HL_LDS) __syncthreads();     // the only barrier: waves are independent from here on
         V.p = smem;
         V.lane = lane;
-        hs.p = shl + lane;
+        hs.p = shl + 4 * lane;
         if (!HL_LDS) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -591,7 +608,7 @@ template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, 
     } else {
         // head weights: registers for a joint net, LDS for split nets (measured: CartPole joint 0.78 vs
         // 0.81 ms with LDS heads; Acrobot split 1.81 -> 1.58 ms with them)
-        if (joint) launch_net<Env, NetF16<OBS, A, true, false>>(a, grid, s);
+        if (joint) launch_net<Env, NetF16<OBS, A, true, PPO_JOINT_HL_LDS>>(a, grid, s);
         else launch_net<Env, NetF16<OBS, A, false, true>>(a, grid, s);
     }
     return ppo_launch_status();

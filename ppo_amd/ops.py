@@ -339,9 +339,10 @@ _TANH_SCALE = 2.0 * 1.4426950408889634   # 2 log2(e): tanh(x) = 1 - 2 / (exp2(_T
 
 
 def _split_f16(x64: torch.Tensor):
-    """x (float64) -> (hi, lo) float16 with x ~= hi + lo / 2048 to 22 bits (rollout.hip, mode 1)."""
+    """x (float64) -> (hi, lo) float16 with x ~= hi + lo (rollout.hip, mode 1); lo may be an f16
+    subnormal, which bounds its error by 2^-25 absolute."""
     hi = x64.to(torch.float16)
-    lo = ((x64 - hi.to(torch.float64)) * 2048.0).to(torch.float16)
+    lo = (x64 - hi.to(torch.float64)).to(torch.float16)
     return hi, lo
 
 

@@ -46,7 +46,7 @@ def test_argument_validation_rejects_before_launch():
                                 None) == INVALID
     assert lib.ppo_adv_stats(None, 5, None, None, 0, None) == INVALID
     assert lib.ppo_categorical_sample(None, 64, 0, 0, 0, None, None, 4, None) == INVALID  # A > 32
-    assert lib.ppo_gae_ragged_workspace_bytes(1000) == 8000
+    assert lib.ppo_gae_ragged_workspace_bytes(1000) == (1000 + 4) * 8   # counts + one total per 256 columns
     assert lib.ppo_loss_workspace_bytes(10) >= 4 * 8
 
 
