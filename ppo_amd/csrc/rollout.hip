@@ -292,6 +292,18 @@ __device__ __forceinline__ float tanh_prescaled(float x2)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x2) + 1.0f), 1.0f);
 }
 
+// two at a time: the add and the fma as packed f32 instructions (one issue slot for two values)
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ void tanh2_prescaled(float x0, float x1, float &a0, float &a1)
+{
+    f32x2 e = {__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1)};
+    e += 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    const f32x2 t = __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
+    a0 = t[0];
+    a1 = t[1];
+}
+
 struct RegW16 {
     Frag16 w1[2][2], w2[4][2][2];
     f32x16 b2[2];
@@ -385,8 +397,8 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
             m = mfma16(w.get1(o, 0), bh, m);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float a0 = tanh_prescaled(m[r]);
-                const float a1 = tanh_prescaled(m[r + 1]);
+                float a0, a1;
+                tanh2_prescaled(m[r], m[r + 1], a0, a1);
                 split2(a0, a1, b2h[e][2 * o + (r >> 3)].w[(r & 7) >> 1], b2l[e][2 * o + (r >> 3)].w[(r & 7) >> 1]);
             }
         }
@@ -413,13 +425,17 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
 #pragma unroll
         for (int op = 0; op < 2; ++op)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float h = tanh_prescaled(m[op][r]);
-                if (DO_P) {
+            for (int r = 0; r < 16; r += 2) {
+                float h[2];
+                tanh2_prescaled(m[op][r], m[op][r + 1], h[0], h[1]);
 #pragma unroll
-                    for (int j = 0; j < A; ++j) p[j][e] = __builtin_fmaf(h, hl.get(j, op, r), p[j][e]);
+                for (int i = 0; i < 2; ++i) {
+                    if (DO_P) {
+#pragma unroll
+                        for (int j = 0; j < A; ++j) p[j][e] = __builtin_fmaf(h[i], hl.get(j, op, r + i), p[j][e]);
+                    }
+                    if (DO_V) p[3][e] = __builtin_fmaf(h[i], hl.get(3, op, r + i), p[3][e]);
                 }
-                if (DO_V) p[3][e] = __builtin_fmaf(h, hl.get(3, op, r), p[3][e]);
             }
     }
 #pragma unroll

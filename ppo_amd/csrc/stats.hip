@@ -24,6 +24,7 @@ constexpr int SEL_T_RET = 7;      // targets 0..6 select from the returns, 7..8 
 constexpr int SEL_B0 = 4096;      // level-0 buckets (top 12 key bits)
 constexpr int SEL_B1 = 1024;      // level-1 / level-2 buckets (10 bits each)
 constexpr int SEL_HBLOCK = 1024;     // histogram kernels: 16 waves share one LDS histogram, 2 blocks fill a CU
+constexpr int SEL_U = 4;             // ring slots a lane has in flight
 
 struct SelState {                 // lives at the head of the workspace
     unsigned long long n;         // number of valid ring entries (same for returns and lengths)
@@ -31,6 +32,9 @@ struct SelState {                 // lives at the head of the workspace
     uint32_t prefix[SEL_T];       // key bits fixed so far (12, then 22, then 32)
     int slot[SEL_T];              // histogram this target reads at the next level (targets that share a prefix share one)
     int leader[SEL_T];            // 1 if slot[t] == t
+    int nlead_ret, nlead;         // the leaders again as two compact lists (returns from entry 0, lengths from SEL_T_RET):
+    uint32_t lprefix[SEL_T];      //   prefix to match,
+    int lslot[SEL_T];             //   histogram to count into
 };
 
 struct SelWs {
@@ -75,31 +79,75 @@ __global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, 
     constexpr int PSHIFT = LEVEL == 1 ? 20 : 10;                       // bits below the fixed prefix
     __shared__ uint32_t h[NH * NB];
     for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK) h[k] = 0u;
-    uint32_t prefix[SEL_T];
-    bool lead[SEL_T];
+    uint32_t lprefix[SEL_T];
+    int lslot[SEL_T], nlead_ret = 0, nlead = 0;
     if (LEVEL > 0) {
         if (w.st->n == 0) return;                                      // uniform: nothing finished yet
+        nlead_ret = __builtin_amdgcn_readfirstlane(w.st->nlead_ret);
+        nlead = __builtin_amdgcn_readfirstlane(w.st->nlead);
 #pragma unroll
-        for (int t = 0; t < SEL_T; ++t) { prefix[t] = w.st->prefix[t]; lead[t] = w.st->leader[t] != 0; }
+        for (int q = 0; q < SEL_T; ++q) {
+            lprefix[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.st->lprefix[q]);
+            lslot[q] = __builtin_amdgcn_readfirstlane(w.st->lslot[q]);
+        }
     }
     __syncthreads();
-    // one ring (env) per wave at a time, lanes across its slots: coalesced, and no per-element
-    // division by the run-time ring length
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (SEL_HBLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (SEL_HBLOCK / 64);
-    for (int n = wave; n < N; n += nwaves) {
-        const int c0 = ring_cnt[n], c = c0 < ring ? c0 : ring;
-        const size_t row = (size_t)n * ring;
-        for (int k = lane; k < c; k += 64) {
-            const uint32_t kr = f2key(ret_ring[row + k]), kl = f2key((float)len_ring[row + k]);
-            if (LEVEL == 0) {
-                atomicAdd(&h[kr >> SHIFT], 1u);
-                atomicAdd(&h[SEL_B0 + (kl >> SHIFT)], 1u);
-            } else {
+    // Flat walk over the N * ring slots: a wave takes 64 SEL_U consecutive slots at a time, lane l
+    // the slots l, l + 64, ...; the (ring, index in ring) pair of the first one costs one division,
+    // the others follow by adding 64 = q64 ring + r64.  A slot is valid if its index in the ring is
+    // below the ring's count.  All 3 SEL_U loads are unconditional (indices clamped into the arrays)
+    // and in flight together; the passes are bound by instruction issue (about 6.5 M slots at
+    // N = 65536), so the per-slot work is kept short: no division, and at levels 1 and 2 only
+    // the distinct prefixes still in play are compared (typically 5 of the 9 targets).
+    const uint32_t total = (uint32_t)N * (uint32_t)ring, uring = (uint32_t)ring;
+    const uint32_t q64 = 64u / uring, r64 = 64u - q64 * uring;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = blockIdx.x * (SEL_HBLOCK / 64) + (threadIdx.x >> 6), nwv = gridDim.x * (SEL_HBLOCK / 64);
+    for (uint32_t b = wv * (64u * SEL_U); b < total; b += nwv * (64u * SEL_U)) {
+        const uint32_t i0 = b + lane;
+        uint32_t n = i0 / uring, k = i0 - n * uring;
+        uint32_t idx[SEL_U], kk[SEL_U];
+        int cnt[SEL_U];
 #pragma unroll
-                for (int t = 0; t < SEL_T; ++t) {
-                    const uint32_t key = t < SEL_T_RET ? kr : kl;
-                    if (lead[t] && (key >> PSHIFT) == prefix[t]) atomicAdd(&h[t * NB + ((key >> SHIFT) & (NB - 1))], 1u);
+        for (int u = 0; u < SEL_U; ++u) {
+            const uint32_t i = i0 + 64u * u;
+            const bool in = i < total;
+            idx[u] = in ? i : total - 1;
+            kk[u] = in ? k : 0xFFFFFFFFu;
+            cnt[u] = ring_cnt[in ? n : 0u];
+            k += r64; n += q64;
+            if (k >= uring) { k -= uring; ++n; }
+        }
+        float r[SEL_U];
+        int l[SEL_U];
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) {
+            r[u] = ret_ring[idx[u]];
+            l[u] = len_ring[idx[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) {
+            const bool act = kk[u] < (uint32_t)(cnt[u] < 0 ? 0 : cnt[u]);
+            const uint32_t kr = f2key(r[u]), kl = f2key((float)l[u]);
+            if (LEVEL == 0) {
+                if (act) {
+                    atomicAdd(&h[kr >> SHIFT], 1u);
+                    atomicAdd(&h[SEL_B0 + (kl >> SHIFT)], 1u);
+                }
+            } else {
+                const uint32_t pr = kr >> PSHIFT, pl = kl >> PSHIFT;
+                const uint32_t dr = (kr >> SHIFT) & (NB - 1), dl = (kl >> SHIFT) & (NB - 1);
+#pragma unroll
+                for (int q = 0; q < SEL_T_RET; ++q) {  // fully unrolled: the list stays in scalar registers
+                    if (q < nlead_ret) {
+                        if (act && pr == lprefix[q]) atomicAdd(&h[lslot[q] * NB + dr], 1u);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SEL_T - SEL_T_RET; ++q) {
+                    if (q < nlead - nlead_ret) {
+                        if (act && pl == lprefix[SEL_T_RET + q]) atomicAdd(&h[lslot[SEL_T_RET + q] * NB + dl], 1u);
+                    }
                 }
             }
         }
@@ -219,6 +267,15 @@ template <int LEVEL> __global__ void __launch_bounds__(SEL_SBLOCK) k_sel_scan(Se
             st->rank[u] = s_rank[u];
             st->prefix[u] = s_prefix[u];
         }
+        int nr = 0, nl = 0;                                  // returns' leaders from entry 0, lengths' from SEL_T_RET
+        for (int u = 0; u < SEL_T; ++u) {
+            if (!st->leader[u]) continue;
+            const int at = u < SEL_T_RET ? nr++ : SEL_T_RET + nl++;
+            st->lprefix[at] = s_prefix[u];
+            st->lslot[at] = u;
+        }
+        st->nlead_ret = nr;
+        st->nlead = nr + nl;
     } else {
         double v[SEL_T];
         for (int u = 0; u < SEL_T; ++u) v[u] = (double)key2f(s_prefix[u]);
@@ -259,7 +316,7 @@ int ppo_episode_stats(const float *ret_ring, const int *len_ring, const int *rin
     hipError_t e = hipMemsetAsync(workspace, 0, SEL_WS_BYTES, s);
     if (e != hipSuccess) return (int)e;
     const SelWs w = sel_ws(workspace);
-    size_t blocks = ((size_t)N + (SEL_HBLOCK / 64) * 4 - 1) / ((SEL_HBLOCK / 64) * 4);   // >= 4 rings per wave
+    size_t blocks = ((size_t)N * ring + SEL_HBLOCK * SEL_U - 1) / (SEL_HBLOCK * SEL_U);
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     int rc = sel_level<0>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
