@@ -238,11 +238,23 @@ struct StepOut {
     int done, trunc;
 };
 
+// A reset draw computed ahead of its use (whole-rollout kernel only).  The draw of env n's next
+// reset is a pure function of (seed, env id, e.episode), so it can be made at any time before that
+// reset.  With a random policy some env of a wave's 64 ends an episode on ~95 % of the steps, and
+// the ~200 instructions of the two Philox calls would run for the whole wave each time; instead
+// every lane without a draw makes one whenever some lane needs one it does not have, which is
+// about every ninth step (a lane that has just used its draw cannot need the next one earlier
+// than its new episode ends).
+struct ResetAhead {
+    double u[4];
+    bool have = false;
+};
+
 // One transition of env n.  Follows gymnasium env.step -> TimeLimit -> RecordEpisodeStatistics and
 // the actor loop of the reference's rollout (src/ppo.py:342-388).
 template <class Env, bool DRAWS = true>
 __device__ __forceinline__ void env_transition(EnvRegs &e, int action, const EnvArgs &a, size_t n, int is_last,
-                                               StepOut &o)
+                                               StepOut &o, ResetAhead *ahead = nullptr)
 {
     const bool terminated = Env::step(e.s, action, o.obs, o.reward);
     e.elapsed += 1;                                          // TimeLimit.step
@@ -268,13 +280,27 @@ __device__ __forceinline__ void env_transition(EnvRegs &e, int action, const Env
     }
     bool can_reset = true;
     if (!ended && is_last) { o.trunc += 1; can_reset = false; }  // src/ppo.py:353-356
-    if (o.done + o.trunc > 0) {                              // src/ppo.py:377-382
+    const bool flagged = o.done + o.trunc > 0;
+    if (ahead) {                                             // compile-time: the caller passes it or not
+        if (__any(flagged && can_reset && !ahead->have)) {
+            if (!ahead->have) {
+                reset_uniform4(a.seed, a.env_base + n, e.episode, ahead->u);
+                ahead->have = true;
+            }
+        }
+    }
+    if (flagged) {                                           // src/ppo.py:377-382
 #pragma unroll
         for (int k = 0; k < 6; ++k) o.term[k] = o.obs[k];
         if (can_reset) {
-            double u[4];
-            draw_reset<DRAWS>(a, n, e.episode, u);
-            Env::reset(e.s, u, o.obs);
+            if (ahead) {
+                Env::reset(e.s, ahead->u, o.obs);
+                ahead->have = false;
+            } else {
+                double u[4];
+                draw_reset<DRAWS>(a, n, e.episode, u);
+                Env::reset(e.s, u, o.obs);
+            }
             e.episode += 1;
             e.elapsed = 0;
         }

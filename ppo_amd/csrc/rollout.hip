@@ -522,6 +522,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 
     EnvRegs e;
     load_env(e, a.env, nn);
+    ResetAhead ahead;
     float obs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < OBS; ++k) obs[k] = a.obs_io[nn * OBS + k];
@@ -559,7 +560,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         o.trunc = 0;
         if (live) {
             if (!(a.ablate & 2)) {
-                env_transition<Env, DRAWS>(e, action, a.env, nn, t == a.T - 1, o);
+                env_transition<Env, DRAWS>(e, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead);
             } else {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o.obs[k] = obs[k] + 1e-3f * (float)action;
