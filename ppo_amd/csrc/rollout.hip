@@ -248,9 +248,10 @@ template <int OBS_, int A_, bool JOINT_> struct NetF32 {
 // ---- network mode 1: f16 MFMA on two-piece splits (f32-grade products at 5x the MFMA rate) -----
 // v_mfma_f32_32x32x2_f32 costs 64 cycles per 2 k and does not overlap with the wave's other VALU
 // work (measured: SQ_VALU_MFMA_COEXEC_CYCLES = 0, issue gaps add up); v_mfma_f32_32x32x16_f16 does
-// 16 k in 32 cycles.  Every operand x is split as x = xh + xl / 2^11 with xh = f16(x) and
-// xl = f16((x - xh) 2^11) (the subtraction is exact), 22 significant bits in all, and a product
-// becomes xh wh + (xh wl + xl wh) / 2^11: three MFMAs into two f32 accumulators, the dropped
+// 16 k in 32 cycles.  Every operand x is split as x = xh + xl with xh = f16(x) (toward zero) and
+// xl = f16(x - xh) (the subtraction is exact), 22 significant bits in all -- xl may be an f16
+// subnormal, which the matrix cores honour: absolute error <= 2^-25 -- and a product becomes
+// xh wl + xl wh + xh wh: three MFMAs into one f32 accumulator (small terms first), the dropped
 // xl wl term being below 2^-22 relative.  f16 x f16 products are exact in the f32 accumulate.
 // The 2 log2(e) factor of tanh's exp2 is folded into the packed weights and biases.
 // Layouts (host: ppo_amd.ops.pack_dense_agent(mode=1)), per backbone, in 32-bit words:
@@ -265,9 +266,6 @@ struct Frag16 {
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int BB16_W1 = 2 * 2 * 64 * 4, BB16_W2 = 4 * 2 * 2 * 64 * 4, BB16_B2 = 2 * 16 * 64;
 constexpr int BB16_WORDS = BB16_W1 + BB16_W2 + BB16_B2;
-#ifndef PPO_JOINT_HL_LDS
-#define PPO_JOINT_HL_LDS true
-#endif
 
 __device__ __forceinline__ f32x16 mfma16(const Frag16 &a, const Frag16 &b, f32x16 c)
 {
@@ -623,9 +621,9 @@ template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, 
         if (joint) launch_net<Env, NetF32<OBS, A, true>>(a, grid, s);
         else launch_net<Env, NetF32<OBS, A, false>>(a, grid, s);
     } else {
-        // head weights: registers for a joint net, LDS for split nets (measured: CartPole joint 0.78 vs
-        // 0.81 ms with LDS heads; Acrobot split 1.81 -> 1.58 ms with them)
-        if (joint) launch_net<Env, NetF16<OBS, A, true, PPO_JOINT_HL_LDS>>(a, grid, s);
+        // head weights in LDS for both: with the MFMA results in VGPRs everything the VALU touches has
+        // to fit 256 registers (measured, CartPole joint: 0.68 ms with register heads, 0.65 ms with LDS heads)
+        if (joint) launch_net<Env, NetF16<OBS, A, true, true>>(a, grid, s);
         else launch_net<Env, NetF16<OBS, A, false, true>>(a, grid, s);
     }
     return ppo_launch_status();
