@@ -299,6 +299,33 @@ def test_episode_statistics_select_edge_cases(case):
     assert ve.median_ep_length == np.percentile(ln[valid], 50.0)
 
 
+@pytest.mark.parametrize("ring,N", [(1, 300), (7, 1000), (63, 129), (64, 64), (65, 500), (100, 70), (130, 257), (257, 33)])
+def test_episode_statistics_any_ring_length(ring, N):
+    """ppo_episode_stats through the C ABI for ring lengths other than the 100 SyncVecEnv uses (the
+    flat walk steps its (ring, index) pairs by 64 = q ring + r): shorter than a wave, equal to it,
+    longer, not a multiple of anything."""
+    from ppo_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(ring * 1000 + N)
+    cnt = rng.integers(0, 3 * ring + 2, N).astype(np.int32)
+    cnt[rng.integers(0, N, 5)] = 0
+    ret = rng.integers(-40, 60, (N, ring)).astype(np.float32) * 0.5
+    ln = rng.integers(1, 501, (N, ring)).astype(np.int32)
+    d_ret, d_len, d_cnt = (torch.from_numpy(x).cuda() for x in (ret, ln, cnt))
+    stats5 = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
+    ws = torch.empty(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    rc = lib.ppo_episode_stats(d_ret.data_ptr(), d_len.data_ptr(), d_cnt.data_ptr(), ring, N, stats5.data_ptr(),
+                               ws.data_ptr(), ws.numel(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = stats5.cpu().numpy()
+    valid = np.arange(ring)[None, :] < np.minimum(cnt, ring)[:, None]
+    want = np.percentile(ret[valid].astype(np.float64), [5.0, 50.0, 95.0])
+    assert got[0] == ret[valid].max()
+    assert np.allclose(got[1:4], want, rtol=1e-12, atol=0.0), (got, want)
+    assert got[4] == np.percentile(ln[valid], 50.0)
+
+
 class _FakeBoxEnv:
     """Host-stepped gym.Env-protocol env with a Box action space (the shape of BASELINE configs 4-5:
     env stepping stays on the host, only GAE and the loss run on the GPU kernels)."""
