@@ -40,6 +40,7 @@ SIGNATURES = {
 _PRIVATE = {
     "ppo_gae_dense_variant": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_stream_ceiling": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
+    "ppo_rollout_wave_envs": (_i, [_i]),
     "ppo_prof_arm": (_i, [_i]),
     "ppo_prof_elapsed_us": (_i, [_i, C.POINTER(C.c_float)]),
 }

@@ -200,7 +200,7 @@ constexpr int ROLLOUT_BLOCK = 256;  // 4 waves, one per SIMD
 
 // ---- network mode 0: f32 MFMA, every product an exact f32 FMA --------------------------------
 template <int OBS_, int A_, bool JOINT_> struct NetF32 {
-    static constexpr int OBS = OBS_, A = A_;
+    static constexpr int OBS = OBS_, A = A_, WAVE_ENVS = 64;
     static constexpr bool JOINT = JOINT_;
     static constexpr int NB = backbone_floats(OBS);
     static constexpr int S1 = ksteps(OBS), S2 = ksteps(H);
@@ -352,12 +352,8 @@ struct LdsW16 {
     }
 };
 
-// Per-lane head weights HL[j][op][r]: in registers, or read from an LDS copy at use (frees up to 128
-// registers; the LDS pipe is otherwise idle in this kernel).
-struct RegHL {
-    float v[4][2][16];
-    __device__ __forceinline__ float get(int j, int op, int r) const { return v[j][op][r]; }
-};
+// Per-lane head weights HL[j][op][r], read from an LDS copy at use (the LDS pipe is otherwise idle
+// in this kernel and the registers are needed elsewhere).
 struct LdsHL {
     const float *p;   // LDS copy of HL as [j][op][r / 4][lane][r % 4], already offset by 4 lane:
                       // four consecutive r are one conflict-free ds_read_b128
@@ -367,7 +363,10 @@ struct LdsHL {
     }
 };
 
-template <int OBS, int A, bool DO_P, bool DO_V, class W, class HLT>
+// ETILES = 2: the wave's 64 lanes are 64 envs, two 32-column MFMA tiles.  ETILES = 1: lanes 0-31 are
+// 32 envs, one tile, lanes 32-63 only hold the other halves of its MFMA operands (their outputs are
+// meaningless): half the network work per wave, for batches too small to give every SIMD a wave of 64.
+template <int OBS, int A, bool DO_P, bool DO_V, int ETILES, class W, class HLT>
 __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w, const HLT &hl, int half,
                                               float (&out)[4])
 {
@@ -379,9 +378,9 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
     Frag16 ih, il;
 #pragma unroll
     for (int i = 0; i < 4; ++i) split2(in[2 * i], in[2 * i + 1], ih.w[i], il.w[i]);
-    Frag16 b2h[2][4], b2l[2][4];     // layer-2 B operands: tanh(h1) pieces, [env tile][k-step]
+    Frag16 b2h[ETILES][4], b2l[ETILES][4];     // layer-2 B operands: tanh(h1) pieces, [env tile][k-step]
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < ETILES; ++e) {
         Frag16 bh, bl;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -406,7 +405,7 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j][0] = p[j][1] = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < ETILES; ++e) {
         // the two output tiles' accumulator chains interleave: each MFMA depends on the one before last
         f32x16 m[2] = {w.bias2(0), w.bias2(1)};
 #pragma unroll
@@ -445,18 +444,20 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
     }
 }
 
-template <int OBS_, int A_, bool JOINT_, bool HL_LDS_> struct NetF16 {
-    static constexpr int OBS = OBS_, A = A_;
-    static constexpr bool JOINT = JOINT_, HL_LDS = HL_LDS_;
+template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
+    static constexpr int OBS = OBS_, A = A_, WAVE_ENVS = 32 * ETILES_;
+    static constexpr bool JOINT = JOINT_;
     static constexpr int HL_WORDS = 4 * 2 * 16 * 64;
-    static constexpr int LDS_WORDS = (JOINT ? 0 : BB16_WORDS) + (HL_LDS ? HL_WORDS : 0) + 4;
+    static constexpr int LDS_WORDS = (JOINT ? 0 : BB16_WORDS) + HL_WORDS + 4;
     RegW16 P;
     LdsW16 V;
-    RegHL hr;
     LdsHL hs;
     float bias4[4];
     int half;
 
+    // Head weights live in LDS for joint and split nets alike: with the MFMA results in VGPRs
+    // everything the VALU touches has to fit 256 registers (measured, CartPole joint: 0.68 ms with
+    // the head weights in registers, 0.65 ms from LDS); split nets keep the value backbone there too.
     __device__ __forceinline__ void load(const float *__restrict__ params, float *smem, int lane)
     {
         half = lane >> 5;
@@ -466,38 +467,22 @@ template <int OBS_, int A_, bool JOINT_, bool HL_LDS_> struct NetF16 {
         if (!JOINT) {
             for (int k = threadIdx.x; k < BB16_WORDS; k += ROLLOUT_BLOCK) smem[k] = params[BB16_WORDS + k];
         }
-        if (HL_LDS) {
-            for (int k = threadIdx.x; k < HL_WORDS; k += ROLLOUT_BLOCK) {     // k = (jo * 16 + r) * 64 + lane
-                const int l = k & 63, r = (k >> 6) & 15, jo = k >> 10;
-                shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = heads[k];
-            }
+        for (int k = threadIdx.x; k < HL_WORDS; k += ROLLOUT_BLOCK) {     // k = (jo * 16 + r) * 64 + lane
+            const int l = k & 63, r = (k >> 6) & 15, jo = k >> 10;
+            shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = heads[k];
         }
-        if (!JOINT || HL_LDS) __syncthreads();     // the only barrier: waves are independent from here on
+        __syncthreads();                           // the only barrier: waves are independent from here on
         V.p = smem;
         V.lane = lane;
         hs.p = shl + 4 * lane;
-        if (!HL_LDS) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int o = 0; o < 2; ++o)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        hr.v[j][o][r] = (j < A || j == 3) ? heads[((j * 2 + o) * 16 + r) * 64 + lane] : 0.0f;
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) bias4[j] = heads[4 * 2 * 16 * 64 + j];
     }
     template <bool DO_P, bool DO_V, bool VNET>
     __device__ __forceinline__ void forward(const float (&obs)[6], float (&out)[4]) const
     {
-        if (HL_LDS) {
-            if (VNET) net_forward16<OBS, A, DO_P, DO_V>(obs, V, hs, half, out);
-            else net_forward16<OBS, A, DO_P, DO_V>(obs, P, hs, half, out);
-        } else {
-            if (VNET) net_forward16<OBS, A, DO_P, DO_V>(obs, V, hr, half, out);
-            else net_forward16<OBS, A, DO_P, DO_V>(obs, P, hr, half, out);
-        }
+        if (VNET) net_forward16<OBS, A, DO_P, DO_V, ETILES_>(obs, V, hs, half, out);
+        else net_forward16<OBS, A, DO_P, DO_V, ETILES_>(obs, P, hs, half, out);
     }
 };
 
@@ -508,11 +493,14 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     constexpr bool JOINT = Net::JOINT;
     static_assert(OBS % 2 == 0 && A <= 3, "fragment layout assumes an even input width and <= 3 actions");
 
+    constexpr int WE = Net::WAVE_ENVS;             // envs per wave: 64, or 32 in lanes 0-31
     const int lane = threadIdx.x & 63;
-    const size_t n = (size_t)blockIdx.x * ROLLOUT_BLOCK + threadIdx.x;
-    // Tail lanes (n >= N) stay: MFMA needs all 64 lanes.  They shadow env N-1 and never store.
-    const bool live = n < (size_t)a.env.N;
-    const size_t nn = live ? n : (size_t)a.env.N - 1;
+    const size_t wave = ((size_t)blockIdx.x * ROLLOUT_BLOCK + threadIdx.x) >> 6;
+    const size_t n = wave * WE + (WE == 64 ? lane : (lane & 31));
+    // Lanes without an env of their own (n >= N, or the upper half of a 32-env wave) stay: MFMA needs
+    // all 64 lanes.  They shadow a valid env and never store.
+    const bool live = n < (size_t)a.env.N && (WE == 64 || lane < 32);
+    const size_t nn = n < (size_t)a.env.N ? n : (size_t)a.env.N - 1;
 
     __shared__ __attribute__((aligned(16))) float smem[Net::LDS_WORDS];
     Net net;
@@ -613,18 +601,31 @@ template <class Env, class Net> void launch_net(const RolloutArgs &a, unsigned g
     else hipLaunchKernelGGL((k_rollout<Env, Net, false>), dim3(grid), dim3(ROLLOUT_BLOCK), 0, s, a, a.params);
 }
 
+// Envs per wave for the f16-split nets: 64, or 32 when the batch is too small to give every SIMD of
+// the chip (256 CUs x 4) a wave of 64 -- twice the waves, each with half the network work.
+// g_wave_envs: 0 = choose by N, 32 / 64 = forced (tests and tuning; ppo_rollout_wave_envs below).
+int g_wave_envs = 0;
+constexpr int HALF_WAVE_MAX_ENVS = 32768;
+
 template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, int net_mode, hipStream_t s)
 {
-    const unsigned grid = (unsigned)((a.env.N + ROLLOUT_BLOCK - 1) / ROLLOUT_BLOCK);
     constexpr int OBS = Env::OBS;
+    const auto grid_for = [&](int wave_envs) {
+        const int per_block = wave_envs * (ROLLOUT_BLOCK / 64);
+        return (unsigned)((a.env.N + per_block - 1) / per_block);
+    };
     if (net_mode == PPO_NET_F32) {
-        if (joint) launch_net<Env, NetF32<OBS, A, true>>(a, grid, s);
-        else launch_net<Env, NetF32<OBS, A, false>>(a, grid, s);
+        if (joint) launch_net<Env, NetF32<OBS, A, true>>(a, grid_for(64), s);
+        else launch_net<Env, NetF32<OBS, A, false>>(a, grid_for(64), s);
     } else {
-        // head weights in LDS for both: with the MFMA results in VGPRs everything the VALU touches has
-        // to fit 256 registers (measured, CartPole joint: 0.68 ms with register heads, 0.65 ms with LDS heads)
-        if (joint) launch_net<Env, NetF16<OBS, A, true, true>>(a, grid, s);
-        else launch_net<Env, NetF16<OBS, A, false, true>>(a, grid, s);
+        const bool half_waves = g_wave_envs ? g_wave_envs == 32 : a.env.N <= HALF_WAVE_MAX_ENVS;
+        if (half_waves) {
+            if (joint) launch_net<Env, NetF16<OBS, A, true, 1>>(a, grid_for(32), s);
+            else launch_net<Env, NetF16<OBS, A, false, 1>>(a, grid_for(32), s);
+        } else {
+            if (joint) launch_net<Env, NetF16<OBS, A, true, 2>>(a, grid_for(64), s);
+            else launch_net<Env, NetF16<OBS, A, false, 2>>(a, grid_for(64), s);
+        }
     }
     return ppo_launch_status();
 }
@@ -632,6 +633,14 @@ template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, 
 }  // namespace
 
 extern "C" {
+
+// tuning / test hook, not in the public header: 0 = choose by N (default), 32 or 64 = forced
+int ppo_rollout_wave_envs(int wave_envs)
+{
+    PPO_REQUIRE(wave_envs == 0 || wave_envs == 32 || wave_envs == 64);
+    g_wave_envs = wave_envs;
+    return 0;
+}
 
 size_t ppo_rollout_param_floats(int kind, int joint, int net_mode)
 {

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import cref, pyref
+from ppo_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -53,18 +54,23 @@ def test_vec_env_rollout(device):
     assert vec_env.global_steps == 250 and vec_env.total_return == np.float32(250.0)
 
 
-@pytest.mark.parametrize("whole", [None, "f32", "f16_split"],
-                         ids=["per_step_kernels", "whole_rollout_f32", "whole_rollout_f16_split"])
+@pytest.mark.parametrize("whole", [None, "f32", "f16_split", "f16_split_wave64"],
+                         ids=["per_step_kernels", "whole_rollout_f32", "whole_rollout_f16_split_wave32",
+                              "whole_rollout_f16_split_wave64"])
 @pytest.mark.parametrize("joint", [1, 0], ids=["joint", "split"])
 @pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
-def test_device_rollout_matches_serial_reference_loop(kind, joint, whole):
+def test_device_rollout_matches_serial_reference_loop(kind, joint, whole, request):
     """Same policy, same sampled actions (replayed), same reset draws (Philox): the fused device
     rollout and the oracle's restatement of the reference's serial loop (src/ppo.py:320-402) give
     the same buffers -- flags exact, the rest to f32 tolerance -- over two consecutive rollouts."""
     from ppo_amd import Agent, SyncVecEnv
     from ppo_amd.envs import DeviceEnv
     torch.manual_seed(0)
-    N, T, seed = (70 if whole == "f16_split" else 64), 96, 2024   # 70: a partial wave (tail lanes shadow env N-1)
+    f16 = whole in ("f16_split", "f16_split_wave64")
+    N, T, seed = (70 if f16 else 64), 96, 2024   # 70: a partial wave (tail lanes shadow env N-1)
+    # small batches run 32 envs per wave (lanes 0-31); force the 64-env form for the last case
+    _lib.load().ppo_rollout_wave_envs(64 if whole == "f16_split_wave64" else 0)
+    request.addfinalizer(lambda: _lib.load().ppo_rollout_wave_envs(0))
     probe = DeviceEnv(kind)
     agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=joint, device="cuda")
     with torch.no_grad():  # away from the near-uniform init so that log-probs / values are non-trivial
