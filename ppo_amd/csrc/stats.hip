@@ -137,18 +137,19 @@ __global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, 
             } else {
                 const uint32_t pr = kr >> PSHIFT, pl = kl >> PSHIFT;
                 const uint32_t dr = (kr >> SHIFT) & (NB - 1), dl = (kl >> SHIFT) & (NB - 1);
+                int sr = -1, sl = -1;
 #pragma unroll
                 for (int q = 0; q < SEL_T_RET; ++q) {  // fully unrolled: the list stays in scalar registers
-                    if (q < nlead_ret) {
-                        if (act && pr == lprefix[q]) atomicAdd(&h[lslot[q] * NB + dr], 1u);
-                    }
+                    if (q < nlead_ret && pr == lprefix[q]) sr = lslot[q];
                 }
 #pragma unroll
                 for (int q = 0; q < SEL_T - SEL_T_RET; ++q) {
-                    if (q < nlead - nlead_ret) {
-                        if (act && pl == lprefix[SEL_T_RET + q]) atomicAdd(&h[lslot[SEL_T_RET + q] * NB + dl], 1u);
-                    }
+                    if (q < nlead - nlead_ret && pl == lprefix[SEL_T_RET + q]) sl = lslot[SEL_T_RET + q];
                 }
+                // prefixes in a list are distinct, so a key matches at most one: one LDS atomic
+                // instruction per key kind (their issue rate is what the pass costs beyond its loads)
+                if (act && sr >= 0) atomicAdd(&h[sr * NB + dr], 1u);
+                if (act && sl >= 0) atomicAdd(&h[sl * NB + dl], 1u);
             }
         }
     }
