@@ -305,6 +305,30 @@ def test_episode_statistics_select_edge_cases(case):
     assert ve.median_ep_length == np.percentile(ln[valid], 50.0)
 
 
+@pytest.mark.parametrize("kind,joint", [("cartpole", 1), ("acrobot", 0)])
+def test_rollout_is_bit_identical_for_both_wave_widths(kind, joint, request):
+    """32 envs per wave (small batches) and 64 envs per wave run the same arithmetic per env: every
+    rollout buffer is bit-identical."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    request.addfinalizer(lambda: _lib.load().ppo_rollout_wave_envs(0))
+    torch.manual_seed(3)
+    probe = DeviceEnv(kind)
+    agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
+    with torch.no_grad():
+        agent.policy.weight.mul_(40.0)
+    got = {}
+    for width in (32, 64):
+        _lib.load().ppo_rollout_wave_envs(width)
+        ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=11), 333, 64, 0, 0.0, agent, seed=11)
+        ve.rollout(); ve.rollout()
+        got[width] = [getattr(ve, k).detach().clone() for k in
+                      ("states", "actions", "log_probs", "values", "rewards", "done_flags", "trunc_flags", "t_states")]
+        got[width].append(ve.end_states.clone())
+    for a, b in zip(got[32], got[64]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("ring,N", [(1, 300), (7, 1000), (63, 129), (64, 64), (65, 500), (100, 70), (130, 257), (257, 33)])
 def test_episode_statistics_any_ring_length(ring, N):
     """ppo_episode_stats through the C ABI for ring lengths other than the 100 SyncVecEnv uses (the
