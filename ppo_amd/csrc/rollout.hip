@@ -10,26 +10,29 @@
 // in launch gaps and in streaming 16 MB hidden activations through HBM for a 0.6 GFLOP problem.
 // Here the activations never leave the register file.
 //
-// Per wave (64 envs) and step the two 64-wide tanh layers run on the matrix cores with
-// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate -- exactly a k-ordered fmaf chain, so no precision
-// is given up).  The layers are CHAINED IN REGISTERS: the D layout of one 32x32 tile (lane = env
-// l & 31, register r = unit (r&3) + 8 (r>>2) + 4 (l>>5)) is, register by register, a valid B
-// operand of the next layer (lane = (k half l >> 5, env l & 31)) for the k-pair
-// (unit(r), unit(r) + 4) -- so the next layer's weights are packed on the host in THAT k order and
-// an accumulator register goes straight from tanh into the next MFMA.  No LDS round trip, no
-// shuffles.  The whole network (72 A-operand fragments + the per-lane head weights) stays in the
-// 512-entry register file for all T steps (one wave per SIMD), so the time-step loop of the joint
-// net touches no LDS at all.  Earlier formulations, measured at N = 65536, T = 128, joint net:
+// Per wave (64 envs, or 32 for small batches) and step the two 64-wide tanh layers run on the matrix
+// cores, in one of two forms (net_mode): v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate -- exactly a
+// k-ordered fmaf chain), or, by default, v_mfma_f32_32x32x16_f16 on two-piece f16 splits of both
+// operands (further down).  In both the layers are CHAINED IN REGISTERS: the D layout of one 32x32
+// tile (lane = env l & 31, register r = unit (r&3) + 8 (r>>2) + 4 (l>>5)) is, register by
+// register, a valid B operand of the next layer for a k order the host is free to choose -- so the
+// next layer's weights are packed on the host in THAT k order and an accumulator register goes
+// straight from tanh into the next MFMA.  No LDS round trip, no shuffles.  The backbone's A-operand
+// fragments stay in the 512-entry register file for all T steps (one wave per SIMD); the f16 form
+// reads the head weights (and a split net's value backbone) from LDS.  Earlier formulations,
+// measured at N = 65536, T = 128, joint net:
 //   - weights as SGPR operands via the scalar cache (VALU dot products)          5.4 ms / rollout
 //   - weights broadcast from LDS with ds_read_b128 (VALU)                         2.9 ms
 //   - MFMA with weights and a [unit][env] activation tile in LDS                  1.56 ms
+//   - f32 MFMA, register-chained (net_mode 0 today)                               1.07 ms
+//   - f16-split MFMA, register-chained (net_mode 1 today)                         0.56 ms
 // The heads are per-lane partial dot products over the 32 units a lane holds, completed with one
 // v_permlane32_swap + add, which also hands every lane the result of ITS env (lane = env again for
 // sampling (Philox) and the fp64 env physics of env_core.h).
 //
-// Bound: MFMA issue (144 x 64 cycles per step, joint net) + the VALU work that does not fit in
-// its shadow.  HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done,
-// trunc).
+// Bound: VALU issue (f16 form: 1243 VALU instructions per wave and step, 70 % of the wave's cycles;
+// the f32 form is bound by its 144 x 64 MFMA cycles, which do not overlap with the wave's VALU
+// work).  HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done, trunc).
 #include "env_core.h"
 #include <cstdlib>
 
@@ -80,7 +83,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ float fast_tanh(float x)
 {
     const float t = __builtin_amdgcn_exp2f(2.8853900817779268f * x);   // exp(2x)
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);   // 2 r is exact: same bits as 1 - 2 r
 }
 
 // lanes 32..63 of a <-> lanes 0..31 of b.  (The compiler builtin for this instruction returns its
