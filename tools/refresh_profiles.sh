@@ -4,6 +4,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 o=gpurun_out/r01/final
+rm -rf $o/prof
 mkdir -p $o
 timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $o/pytest_gpu.txt 2>&1 || { tail -20 $o/pytest_gpu.txt; exit 1; }
 tail -2 $o/pytest_gpu.txt
