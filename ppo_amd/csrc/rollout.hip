@@ -360,9 +360,9 @@ struct LdsW16 {
 struct LdsHL {
     const float *p;   // LDS copy of HL as [j][op][r / 4][lane][r % 4], already offset by 4 lane:
                       // four consecutive r are one conflict-free ds_read_b128
-    __device__ __forceinline__ float get(int j, int op, int r) const
+    __device__ __forceinline__ float4 get4(int j, int op, int r4) const
     {
-        return p[((j * 2 + op) * 4 + (r >> 2)) * 256 + (r & 3)];
+        return *reinterpret_cast<const float4 *>(p + ((j * 2 + op) * 4 + r4) * 256);
     }
 };
 
@@ -409,6 +409,11 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
     for (int j = 0; j < 4; ++j) p[j][0] = p[j][1] = 0.0f;
 #pragma unroll
     for (int e = 0; e < ETILES; ++e) {
+        // first group of head weights: requested before the MFMA chain, in registers when it ends
+        float4 wn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((j < A && DO_P) || (j == 3 && DO_V)) wn[j] = hl.get4(j, 0, 0);
         // the two output tiles' accumulator chains interleave: each MFMA depends on the one before last
         f32x16 m[2] = {w.bias2(0), w.bias2(1)};
 #pragma unroll
@@ -422,21 +427,30 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int op = 0; op < 2; ++op) m[op] = mfma16(w.get2(j, op, 0), b2h[e][j], m[op]);
+        // heads: four units at a time; the weights of the next group are requested from LDS before
+        // the current group is consumed, so that the read latency hides behind its tanh work
 #pragma unroll
-        for (int op = 0; op < 2; ++op)
+        for (int g = 0; g < 8; ++g) {
+            const int op = g >> 2, r0 = 4 * (g & 3);
+            float4 wc[4];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float h[2];
-                tanh2_prescaled(m[op][r], m[op][r + 1], h[0], h[1]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (DO_P) {
-#pragma unroll
-                        for (int j = 0; j < A; ++j) p[j][e] = __builtin_fmaf(h[i], hl.get(j, op, r + i), p[j][e]);
-                    }
-                    if (DO_V) p[3][e] = __builtin_fmaf(h[i], hl.get(3, op, r + i), p[3][e]);
+            for (int j = 0; j < 4; ++j)
+                if ((j < A && DO_P) || (j == 3 && DO_V)) {
+                    wc[j] = wn[j];
+                    if (g + 1 < 8) wn[j] = hl.get4(j, (g + 1) >> 2, (g + 1) & 3);
                 }
-            }
+            float h[4];
+            tanh2_prescaled(m[op][r0], m[op][r0 + 1], h[0], h[1]);
+            tanh2_prescaled(m[op][r0 + 2], m[op][r0 + 3], h[2], h[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((j < A && DO_P) || (j == 3 && DO_V)) {
+                    p[j][e] = __builtin_fmaf(h[0], wc[j].x, p[j][e]);
+                    p[j][e] = __builtin_fmaf(h[1], wc[j].y, p[j][e]);
+                    p[j][e] = __builtin_fmaf(h[2], wc[j].z, p[j][e]);
+                    p[j][e] = __builtin_fmaf(h[3], wc[j].w, p[j][e]);
+                }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
