@@ -191,6 +191,7 @@ class SyncVecEnv:
         self._stats_dev = None
         self._stats_pending = False
         self._stats5 = None
+        self._rsum_pool, self._rsum_next = torch.empty(0), 0
         self._packed = (None, None)
         self._total_return = np.float32(0.0)
         self._end_states = None
@@ -304,7 +305,12 @@ class SyncVecEnv:
             if self._ev_dense is None or self._ev_dense.shape != self.rewards.shape:
                 self._ev_dense = torch.empty_like(self.rewards)
             carry = self.t_states.contiguous()         # obs_io: read at t = 0, overwritten with the carried obs
-            rsum = torch.zeros(1, dtype=torch.float64, device=kdev)   # fresh per rollout: read lazily later
+            # reward-sum cell of this rollout (read lazily later): cells come zeroed 64 at a time, so
+            # that a rollout does not pay for a fill launch of its own
+            if self._rsum_next >= self._rsum_pool.numel():
+                self._rsum_pool, self._rsum_next = torch.zeros(64, dtype=torch.float64, device=kdev), 0
+            rsum = self._rsum_pool[self._rsum_next:self._rsum_next + 1]
+            self._rsum_next += 1
             ops.rollout_fused(b, self._packed_params(), self.agent.joint_net, self._rollouts * T, carry,
                               self.states, self.actions, self.log_probs, self.values, self.rewards,
                               self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T,
