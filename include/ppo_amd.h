@@ -250,7 +250,10 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
  * interpolation like np.percentile, exact (a radix select over the valid ring slots; nothing is
  * sorted).  Left untouched while no episode has finished, so initialise stats5 to NaN
  * (src/ppo.py:250-254); stats5[0] is a running maximum across calls (:408-410).
- * workspace: ppo_episode_stats_workspace_bytes() bytes of device memory, 8-byte aligned.
+ * workspace: ppo_episode_stats_workspace_bytes() bytes of device memory, 8-byte aligned, ZERO-FILLED
+ * by the caller once after allocating it; every call leaves it zero-filled for the next one (the
+ * kernels clear what they have consumed, which saves a memset launch per call).  Do not share one
+ * workspace between calls that may overlap.
  */
 size_t ppo_episode_stats_workspace_bytes(void);
 int ppo_episode_stats(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring,

@@ -248,7 +248,12 @@ template <int LEVEL> __global__ void __launch_bounds__(SEL_SBLOCK) k_sel_scan(Se
         prefix = (uint32_t)wb.find(rank);
     } else {
         n = st->n;
-        if (n == 0) return;
+        if (n == 0) return;                                      // nothing was counted: all histograms are still zero
+        // The histograms this level does not read are cleared here for the next call (level 1: hist0,
+        // consumed by level 0's narrowing; level 2: hist1), and level 2 clears its own after the reads
+        // below: a call finds the workspace zeroed and leaves it zeroed, without a memset launch.
+        uint32_t *stale = LEVEL == 1 ? w.hist0 : w.hist1;
+        for (int k = threadIdx.x; k < (LEVEL == 1 ? 2 * SEL_B0 : SEL_T * SEL_B1); k += SEL_SBLOCK) stale[k] = 0u;
         WaveBins<SEL_B1 / 64> wb;
         wb.load((LEVEL == 1 ? w.hist1 : w.hist2) + st->slot[t] * SEL_B1);
         rank = st->rank[t];
@@ -256,6 +261,9 @@ template <int LEVEL> __global__ void __launch_bounds__(SEL_SBLOCK) k_sel_scan(Se
     }
     if (lane == 0) { s_rank[t] = rank; s_prefix[t] = prefix; }
     __syncthreads();
+    if (LEVEL == 2) {
+        for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_SBLOCK) w.hist2[k] = 0u;
+    }
     if (threadIdx.x != 0) return;
     if (LEVEL < 2) {                                         // targets with equal prefixes share a histogram
         st->n = n;
@@ -314,9 +322,7 @@ int ppo_episode_stats(const float *ret_ring, const int *len_ring, const int *rin
     if (N == 0) return 0;
     PPO_REQUIRE(ret_ring && len_ring && ring_cnt);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, SEL_WS_BYTES, s);
-    if (e != hipSuccess) return (int)e;
-    const SelWs w = sel_ws(workspace);
+    const SelWs w = sel_ws(workspace);               // zero-filled by the caller once; every call leaves it zeroed
     size_t blocks = ((size_t)N * ring + SEL_HBLOCK * SEL_U - 1) / (SEL_HBLOCK * SEL_U);
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;

@@ -400,7 +400,7 @@ class SyncVecEnv:
         lib = ops._lib.load()
         if self._stats5 is None:
             self._stats5 = torch.full((5,), float("nan"), dtype=torch.float64, device=b.device)
-            self._stats_ws = torch.empty(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device=b.device)
+            self._stats_ws = torch.zeros(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device=b.device)
         ops._lib.check(lib.ppo_episode_stats(b.ret_ring.data_ptr(), b.len_ring.data_ptr(), b.ring_cnt.data_ptr(),
                                              b.ring, b.num_envs, self._stats5.data_ptr(), self._stats_ws.data_ptr(),
                                              self._stats_ws.numel(), ops._stream()), "ppo_episode_stats")

@@ -343,11 +343,13 @@ def test_episode_statistics_any_ring_length(ring, N):
     ln = rng.integers(1, 501, (N, ring)).astype(np.int32)
     d_ret, d_len, d_cnt = (torch.from_numpy(x).cuda() for x in (ret, ln, cnt))
     stats5 = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
-    ws = torch.empty(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device="cuda")
-    rc = lib.ppo_episode_stats(d_ret.data_ptr(), d_len.data_ptr(), d_cnt.data_ptr(), ring, N, stats5.data_ptr(),
-                               ws.data_ptr(), ws.numel(), None)
-    assert rc == 0
+    ws = torch.zeros(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device="cuda")   # zeroed once
+    for _ in range(2):                               # the second call runs on the workspace as the first left it
+        rc = lib.ppo_episode_stats(d_ret.data_ptr(), d_len.data_ptr(), d_cnt.data_ptr(), ring, N, stats5.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), None)
+        assert rc == 0
     torch.cuda.synchronize()
+    assert int(ws[512:].count_nonzero()) == 0        # histograms cleared for the next call
     got = stats5.cpu().numpy()
     valid = np.arange(ring)[None, :] < np.minimum(cnt, ring)[:, None]
     want = np.percentile(ret[valid].astype(np.float64), [5.0, 50.0, 95.0])
