@@ -305,6 +305,54 @@ def test_episode_statistics_select_edge_cases(case):
     assert ve.median_ep_length == np.percentile(ln[valid], 50.0)
 
 
+@pytest.mark.parametrize("wave_envs", [32, 64])
+@pytest.mark.parametrize("joint", [1, 0], ids=["joint", "split"])
+@pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
+def test_fused_rollout_bootstraps_time_limit_truncations(kind, joint, wave_envs, request):
+    """TimeLimit truncations in the middle of a rollout (reference: gymnasium TimeLimit + src/ppo.py:377-379,
+    :555, :478): the whole-rollout kernel raises trunc at elapsed == 500, records the terminal observation,
+    resets the env, and writes V(terminal observation) from its own second network pass.  Checked against
+    the PyTorch critic on the recorded terminal observations."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    request.addfinalizer(lambda: _lib.load().ppo_rollout_wave_envs(0))
+    _lib.load().ppo_rollout_wave_envs(wave_envs)
+    torch.manual_seed(5)
+    N, T = 200, 64
+    probe = DeviceEnv(kind)
+    agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
+    with torch.no_grad():
+        agent.critic.bias.fill_(0.7)
+    ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=9), N, T, 0, 0.0, agent, seed=9)
+    rng = np.random.default_rng(0)
+    left = rng.integers(1, T - 1, N).astype(np.int32)          # steps until the time limit, per env
+    ve.batch.elapsed.copy_(torch.from_numpy(500 - left))
+    ve.rollout()
+    tr, dn = ve.trunc_flags.cpu().numpy(), ve.done_flags.cpu().numpy()
+    alive = np.array([dn[:left[n] - 1, n].sum() == 0 for n in range(N)])   # not terminated before its limit
+    assert alive.sum() > (0 if kind == "cartpole" else N // 2)
+    for n in np.nonzero(alive)[0]:
+        assert tr[left[n] - 1, n] == 1                            # the step that reaches elapsed == 500
+    mid = torch.from_numpy(tr[:-1] > 0).cuda()
+    assert int(mid.sum()) >= int(alive.sum())
+    term = ve._term_obs[:-1][mid]
+    with torch.no_grad():
+        want = agent.get_values(term)
+    got = ve._ev_dense[:-1][mid]
+    assert torch.allclose(got, want, rtol=1e-5, atol=2e-6)
+    # the forced truncation of the last row is bootstrapped as well
+    last = ve.trunc_flags[-1] > 0
+    with torch.no_grad():
+        want_last = agent.get_values(ve._term_obs[-1][last])
+    assert torch.allclose(ve._ev_dense[-1][last], want_last, rtol=1e-5, atol=2e-6)
+    # and the env restarted: the row after a truncation holds a fresh reset observation
+    nxt = ve.states.detach()[1:][mid]
+    bound = 0.05 if kind == "cartpole" else 1.0
+    assert float(nxt.abs().max()) <= bound + 1e-6
+    if kind == "acrobot":
+        assert float(nxt[:, 4:].abs().max()) <= 0.1 + 1e-6          # velocities drawn from U(-0.1, 0.1)
+
+
 @pytest.mark.parametrize("kind,joint", [("cartpole", 1), ("acrobot", 0)])
 def test_rollout_is_bit_identical_for_both_wave_widths(kind, joint, request):
     """32 envs per wave (small batches) and 64 envs per wave run the same arithmetic per env: every
