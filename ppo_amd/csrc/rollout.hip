@@ -535,7 +535,26 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     // Everything loaded above has arrived before the loop starts, so that no vmcnt wait is needed
     // inside it: there it would also wait for the previous step's stores (vmcnt counts both).
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), other counters untouched
+    int pend_t = -1;                               // row of this env's truncation still waiting for its bootstrap value
+    // Second network pass over the terminal observations of the envs with a pending truncation
+    auto settle = [&]() {
+        const bool has = pend_t >= 0;
+        float tobs[6];
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // this wave's term_obs stores have landed (rare path)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tobs[k] = obs[k];
+        if (has) {
+#pragma unroll
+            for (int k = 0; k < OBS; ++k) tobs[k] = a.term_obs[((size_t)pend_t * N + n) * OBS + k];
+        }
+        float ev[4] = {0.f, 0.f, 0.f, 0.f};
+        net.template forward<false, true, !JOINT>(tobs, ev);
+        if (has) a.ev_dense[(size_t)pend_t * N + n] = ev[3] + net.bias4[3];
+        pend_t = -1;
+    };
     for (int t = 0; t < a.T; ++t) {
+        StepOut o;
+        o.trunc = 0;
         // ---- backbone(s) + heads (src/ppo.py:126-145, :174-182)
         float out[4] = {0.f, 0.f, 0.f, 0.f};
         if (!(a.ablate & 1)) {
@@ -559,8 +578,6 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
             action = lg[0] > lg[1]; logp = lg[0];
         }
 
-        StepOut o;
-        o.trunc = 0;
         if (live) {
             if (!(a.ablate & 2)) {
                 env_transition<Env, DRAWS>(e, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead);
@@ -584,24 +601,23 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
             a.trunc[row] = o.trunc;
             if (o.done + o.trunc > 0) store_obs<Env>(a.term_obs, row, o.term);
         }
+        const bool need_ev = a.ev_dense != nullptr && live && o.trunc > 0;
         // ---- bootstrap value of the terminal observation for truncated episodes: what the
         // reference gets from agent.get_values(end_states) (src/ppo.py:555) and uses where
-        // trunc != 0 (:478).  Wave-uniform branch: taken when any of the 64 envs truncated (always
-        // at the forced last step, ~1/8 of the other steps for a policy that reaches the 500-step limit).
-        const bool need_ev = a.ev_dense != nullptr && live && o.trunc > 0;
-        if (__any(need_ev)) {
-            float tobs[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) tobs[k] = need_ev ? o.term[k] : obs[k];
-            float ev[4] = {0.f, 0.f, 0.f, 0.f};
-            net.template forward<false, true, !JOINT>(tobs, ev);
-            if (need_ev) a.ev_dense[(size_t)t * N + n] = ev[3] + net.bias4[3];
-        }
+        // trunc != 0 (:478).  A second network pass for the whole wave -- so it is deferred: an env
+        // remembers the row of its truncation (the terminal observation is in term_obs already), and
+        // the pass runs when an env truncates again before its earlier one is settled (at the forced
+        // truncation of the last row, for envs that also hit the time limit earlier) and once after
+        // the loop: one or two passes per rollout instead of one on every step on which some env
+        // of the wave reaches the 500-step limit (~1/8 of the steps for long episodes).
+        if (__any(pend_t >= 0 && need_ev)) settle();
+        if (need_ev) pend_t = t;
         if (live) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) obs[k] = o.obs[k];
         }
     }
+    if (__any(pend_t >= 0)) settle();
     if (live) {
         store_env(e, a.env, n);
         store_obs<Env>(a.obs_io, n, obs);
