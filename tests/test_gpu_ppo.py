@@ -353,6 +353,28 @@ def test_fused_rollout_bootstraps_time_limit_truncations(kind, joint, wave_envs,
         assert float(nxt[:, 4:].abs().max()) <= 0.1 + 1e-6          # velocities drawn from U(-0.1, 0.1)
 
 
+def test_fused_rollout_settles_repeated_truncations_of_one_env():
+    """A rollout longer than two time limits: an env hits the 500-step limit, then hits it again (or
+    reaches the forced truncation of the last row) while the first bootstrap value is still pending --
+    the kernel has to settle the earlier one first.  Every truncated cell gets V(terminal observation)."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    torch.manual_seed(6)
+    N, T = 96, 1100
+    probe = DeviceEnv("acrobot")
+    agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
+    with torch.no_grad():
+        agent.critic.bias.fill_(-0.4)
+    ve = SyncVecEnv(lambda: DeviceEnv("acrobot", seed=4), N, T, 0, 0.0, agent, seed=4)
+    ve.rollout()
+    tr = ve.trunc_flags > 0
+    per_env = tr.sum(0)
+    assert int(per_env.max()) >= 3                    # two time limits and the last row, for some env
+    with torch.no_grad():
+        want = agent.get_values(ve._term_obs[tr])
+    assert torch.allclose(ve._ev_dense[tr], want, rtol=1e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize("kind,joint", [("cartpole", 1), ("acrobot", 0)])
 def test_rollout_is_bit_identical_for_both_wave_widths(kind, joint, request):
     """32 envs per wave (small batches) and 64 envs per wave run the same arithmetic per env: every
