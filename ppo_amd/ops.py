@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -383,8 +385,9 @@ def _backbone_f16_split(seq) -> list:
     return [w1.reshape(-1), w2.reshape(-1), bb.reshape(-1)]
 
 
-def pack_dense_agent(agent, net_mode: int = NET_F32) -> torch.Tensor:
-    """Flatten a dense Agent's parameters into the layout k_rollout reads (rollout.hip): per
+def pack_dense_agent_reference(agent, net_mode: int = NET_F32) -> torch.Tensor:
+    """Straightforward form of pack_dense_agent (dozens of small tensor ops; the definition the
+    planned form below is tested against).  Flatten a dense Agent's parameters into the layout k_rollout reads (rollout.hip): per
     backbone the MFMA fragments of both tanh layers -- f32 fragments, the second layer in
     register-chained k order (NET_F32), or two-piece f16 splits of the 2 log2(e)-scaled weights
     (NET_F16_SPLIT) -- then the per-lane head weights HL[4][2][16][64] (j = 0..2 logits zero padded,
@@ -413,6 +416,134 @@ def pack_dense_agent(agent, net_mode: int = NET_F32) -> torch.Tensor:
         bias4[3] = agent.critic.bias[0]
         parts += [hl.reshape(-1), bias4]
         return torch.cat([p.detach().to(torch.float32).reshape(-1) for p in parts]).contiguous()
+
+
+class _PackPlan:
+    """pack_dense_agent as a handful of gathers.  The layout never changes for a given network shape,
+    so it is worked out once -- by running the reference packing code on tensors of INDICES into the
+    flattened parameter vector instead of on values -- and a pack is then: concatenate the
+    parameters, gather, scale, split into f16 pieces, gather into place.  (The step-by-step form
+    costs 0.6-1.0 ms of small launches per rollout in training, as much as the rollout kernel.)"""
+
+    def __init__(self, agent, net_mode):
+        dev = agent.policy.weight.device
+        self.names = [n for n, _ in agent.named_parameters()]
+        shapes = {n: p.shape for n, p in agent.named_parameters()}
+        offs, total = {}, 0
+        for n in self.names:
+            offs[n] = total
+            total += int(np.prod(shapes[n]))
+        self.pad = total                                   # index of the appended 0.0
+
+        def idx(name):
+            return (offs[name] + torch.arange(int(np.prod(shapes[name])), device=dev)).reshape(shapes[name])
+
+        def seq_idx(prefix):                               # Sequential(Linear, Tanh, Linear, Tanh)
+            return idx(prefix + ".0.weight"), idx(prefix + ".0.bias"), idx(prefix + ".2.weight"), idx(prefix + ".2.bias")
+
+        lane = torch.arange(64, device=dev)
+        half, l31 = lane >> 5, lane & 31
+        pad = self.pad
+        seg16, seg32 = [], []                              # (src, is_lo) element lists; (src, scale) lists
+        order = []                                         # final layout: ("h", n_words) / ("f", n_floats) in sequence
+        backbones = ["pi_backbone"] + ([] if agent.joint_net else ["va_backbone"])
+        for bbn in backbones:
+            W1, b1, W2, b2 = seq_idx(bbn)
+            obs = W1.shape[1]
+            if net_mode == NET_F16_SPLIT:
+                assert obs < 8
+                a1 = torch.full((2, 64, 8), pad, dtype=torch.long, device=dev)
+                for op in range(2):
+                    a1[op, :, :obs] = W1[32 * op + l31]
+                    a1[op, :, obs] = b1[32 * op + l31]
+                j = torch.arange(4, device=dev)[:, None, None]
+                i = torch.arange(8, device=dev)[None, None, :]
+                unit = _d_layout_unit(j >> 1, 8 * (j & 1) + i, half[None, :, None])
+                a2 = torch.stack([W2[(32 * op + l31)[None, :, None], unit] for op in range(2)], dim=1)   # [j, op, lane, 8]
+                for src, piece_dim in ((a1, 1), (a2, 2)):
+                    e = torch.stack([src, src], dim=piece_dim)                  # hi block, lo block
+                    lo = torch.zeros_like(e, dtype=torch.bool)
+                    lo.select(piece_dim, 1).fill_(True)
+                    seg16.append((e.reshape(-1), lo.reshape(-1)))
+                    order.append(("h", e.numel() // 2))
+                o = torch.arange(2, device=dev)[:, None, None]
+                r = torch.arange(16, device=dev)[None, :, None]
+                bsrc = b2[_d_layout_unit(o, r, half[None, None, :])].reshape(-1)
+                seg32.append((bsrc, torch.full_like(bsrc, 0, dtype=torch.float64) + _TANH_SCALE))
+                order.append(("f", bsrc.numel()))
+            else:
+                for W, b, chained in ((W1, b1, False), (W2, b2, True)):
+                    K = W.shape[1]
+                    if K % 2:
+                        W = torch.cat([W, torch.full((64, 1), pad, dtype=torch.long, device=dev)], dim=1)
+                        K += 1
+                    sidx = torch.arange(K // 2, device=dev)
+                    if chained:
+                        col = _d_layout_unit((sidx // 16)[:, None], (sidx % 16)[:, None], half[None, :])
+                    else:
+                        col = 2 * sidx[:, None] + half[None, :]
+                    frag = torch.full((1 + K // 2, 2, 64), pad, dtype=torch.long, device=dev)
+                    for o in range(2):
+                        frag[0, o] = torch.where(half == 0, b[32 * o + l31], torch.full_like(l31, pad))
+                        frag[1:, o] = W[(32 * o + l31)[None, :], col]
+                    seg32.append((frag.reshape(-1), torch.ones(frag.numel(), dtype=torch.float64, device=dev)))
+                    order.append(("f", frag.numel()))
+        A = shapes["policy.weight"][0]
+        assert A <= 3
+        wh = torch.full((4, 64), pad, dtype=torch.long, device=dev)
+        wh[:A] = idx("policy.weight")
+        wh[3] = idx("critic.weight").reshape(-1)
+        o = torch.arange(2, device=dev)[:, None, None]
+        r = torch.arange(16, device=dev)[None, :, None]
+        hl = wh[:, _d_layout_unit(o, r, (lane >> 5)[None, None, :])].reshape(-1)
+        bias4 = torch.full((4,), pad, dtype=torch.long, device=dev)
+        bias4[:A] = idx("policy.bias")
+        bias4[3] = idx("critic.bias")[0]
+        tail = torch.cat([hl, bias4])
+        seg32.append((tail, torch.ones(tail.numel(), dtype=torch.float64, device=dev)))
+        order.append(("f", tail.numel()))
+        # element lists, and where each output word comes from in cat([f16 words, f32 values])
+        self.src16 = torch.cat([e for e, _ in seg16]) if seg16 else None
+        self.lo16 = torch.cat([m for _, m in seg16]) if seg16 else None
+        self.src32 = torch.cat([e for e, _ in seg32])
+        self.scale32 = torch.cat([c for _, c in seg32])
+        n_words = 0 if self.src16 is None else self.src16.numel() // 2
+        perm, at_h, at_f = [], 0, n_words
+        for kind, n in order:
+            if kind == "h":
+                perm.append(torch.arange(at_h, at_h + n, device=dev)); at_h += n
+            else:
+                perm.append(torch.arange(at_f, at_f + n, device=dev)); at_f += n
+        self.perm = torch.cat(perm)
+
+    def pack(self, agent) -> torch.Tensor:
+        params = dict(agent.named_parameters())
+        flat = [params[n].detach().reshape(-1) for n in self.names]
+        theta = torch.cat(flat + [flat[0].new_zeros(1)]).to(torch.float64)
+        parts = []
+        if self.src16 is not None:
+            v = theta[self.src16] * _TANH_SCALE
+            hi = v.to(torch.float16)
+            lo = (v - hi.to(torch.float64)).to(torch.float16)
+            parts.append(torch.where(self.lo16, lo, hi).view(torch.float32))
+        parts.append((theta[self.src32] * self.scale32).to(torch.float32))
+        return torch.cat(parts)[self.perm].contiguous()
+
+
+_PACK_PLANS: dict = {}
+
+
+def pack_dense_agent(agent, net_mode: int = NET_F32) -> torch.Tensor:
+    """Flatten a dense Agent's parameters into the layout k_rollout reads (rollout.hip; element by
+    element the same as pack_dense_agent_reference).  The gather plan is cached per network shape,
+    mode and device."""
+    key = (int(net_mode), bool(agent.joint_net), str(agent.policy.weight.device),
+           tuple((n, tuple(p.shape)) for n, p in agent.named_parameters()))
+    plan = _PACK_PLANS.get(key)
+    if plan is None:
+        plan = _PACK_PLANS[key] = _PackPlan(agent, net_mode)
+    with torch.no_grad():
+        return plan.pack(agent)
 
 
 def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, log_probs, values, rewards, done,

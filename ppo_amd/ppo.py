@@ -576,6 +576,7 @@ class PPO:
         num_envs, steps_per_env = ve.num_envs, ve.steps_per_env
         world = ppo_dist.world_size()
 
+        _sync()                                    # the previous update's kernels are not part of this bracket
         rollout_start = time.time()
         ve.rollout()
         with torch.no_grad():
