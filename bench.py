@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense BF16/FP16 MFMA
 GAE_BYTES_PER_ELEM = 20        # r, v, done, trunc read + adv written; the end value is read only where
                                # trunc != 0 (4 B more for those cells).  SURVEY.md 8d's dense count is 24.
 
@@ -164,6 +165,24 @@ def main():
     elapsed_f32 = max_over_ranks(time.perf_counter() - t0)
     ve.net_mode = ops.NET_F16_SPLIT
 
+    # The rollout kernel alone (it is ~85 % of a step): a few more rollouts with an event pair around
+    # the launch, outside the timed region -- an event pair inside it would add barrier packets.
+    pairs = []
+    for _ in range(8):                             # back to back like the timed steps (an idle GPU clocks higher)
+        ve._flush_stats()                          # the previous rollout's statistics kernels stay outside the pair
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ve.rollout()
+        e1.record()
+        pairs.append((e0, e1))
+        ops.gae_dense(ve.rewards, ve.values, ve._ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95)
+    torch.cuda.synchronize()
+    ro_ms = float(np.median([a.elapsed_time(b) for a, b in pairs[2:]]))
+    waves = (N + 63) // 64 if N > 32768 else (N + 31) // 32          # 64- or 32-env waves (csrc/rollout.hip)
+    mfma_per_wave_step = 60 if N > 32768 else 30                      # 32x32x16 f16 MFMAs, joint net
+    ro_flops = mfma_per_wave_step * 2 * 32 * 32 * 16 * waves * T
+    ro_bytes = (4 * probe.observation_space.shape[0] + 24) * N * T    # states + action, log-prob, value, reward, 2 flags
+
     us = C.c_float()
     gae_us = []
     for slot in gae_events:
@@ -206,6 +225,16 @@ def main():
                                  "4 rotating buffer sets) the same kernel takes 35.8 us = 58.7 % of peak, and `traffic` "
                                  "is the L2-to-fabric byte count of that cold run"},
         }
+        line["rollout_kernel"] = {
+            "kernel": "k_rollout (ppo_rollout_fused), PPO_NET_F16_SPLIT", "bound": "valu-issue",
+            "avg_launch_us": ro_ms * 1e3,
+            "mfma_f16_tflops": ro_flops / (ro_ms * 1e-3) / 1e12, "mfma_f16_peak_tflops": MFMA_F16_PEAK_TFLOPS,
+            "mfma_frac": ro_flops / (ro_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+            "hbm_write_gbs": ro_bytes / (ro_ms * 1e-3) / 1e9,
+            "note": "neither an HBM- nor an MFMA-bound kernel: by PMC (profiles/r01_rollout_pmc_f16_split.txt) "
+                    "the VALU is active 70 % of the wave cycles (tanh, operand splits, heads, f64 physics, "
+                    "Philox), the 60 f16 MFMAs per wave and step are busy 21 %; event pair around the launch in a "
+                    "back-to-back loop after the timed region, median of 6"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, args.cpu_sample_envs, T, args.seed)
         print(json.dumps(line), flush=True)
