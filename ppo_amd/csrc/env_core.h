@@ -334,17 +334,23 @@ __device__ __forceinline__ void store_env(const EnvRegs &e, const EnvArgs &a, si
 // Categorical(logits) sample + log-prob for env `id` at policy step `step` (reference
 // src/ppo.py:186-189,212).  Key half 1 is offset so this stream never collides with the reset
 // stream of the same seed.
-__device__ __forceinline__ void categorical_sample(const float *lg, int A, uint64_t seed, uint64_t id, uint64_t step,
-                                                   int &action, float &logp)
+// The uniform draw of (seed; env id, policy step): it depends on nothing the network computes, so the
+// whole-rollout kernel makes it before the forward pass, where its ten dependent Philox rounds fill
+// VALU slots in the shadow of the first MFMAs instead of sitting between the logits and the action.
+__device__ __forceinline__ float sample_uniform(uint64_t seed, uint64_t id, uint64_t step)
+{
+    const Philox4 rnd = philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)step, (uint32_t)(step >> 32),
+                                      (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
+    return (float)(rnd.v[0] >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+}
+
+__device__ __forceinline__ void categorical_from_uniform(const float *lg, int A, float u, int &action, float &logp)
 {
     float mx = lg[0];
     for (int k = 1; k < A; ++k) mx = fmaxf(mx, lg[k]);
     float sum = 0.0f;
     for (int k = 0; k < A; ++k) sum += expf(lg[k] - mx);
     const float lse = mx + logf(sum);
-    const Philox4 rnd = philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)step, (uint32_t)(step >> 32),
-                                      (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
-    const float u = (float)(rnd.v[0] >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
     const float target = u * sum;
     float cdf = 0.0f;
     int pick = A - 1;
@@ -356,6 +362,12 @@ __device__ __forceinline__ void categorical_sample(const float *lg, int A, uint6
     }
     action = pick;
     logp = lpick - lse;
+}
+
+__device__ __forceinline__ void categorical_sample(const float *lg, int A, uint64_t seed, uint64_t id, uint64_t step,
+                                                   int &action, float &logp)
+{
+    categorical_from_uniform(lg, A, sample_uniform(seed, id, step), action, logp);
 }
 
 }  // namespace ppo_env

@@ -38,6 +38,14 @@
 
 using namespace ppo_env;
 
+// The ablation switches (PPO_ROLLOUT_ABLATE) are compiled in only on request: as run-time branches
+// they cut the step into basic blocks and keep the scheduler from interleaving across them.
+#ifdef PPO_ROLLOUT_ABLATE_BUILD
+#define ABLATE(args) ((args).ablate)
+#else
+#define ABLATE(args) 0
+#endif
+
 namespace {
 
 constexpr int H = 64;  // hidden width of the reference's dense net (src/ppo.py:127-129)
@@ -555,9 +563,11 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     for (int t = 0; t < a.T; ++t) {
         StepOut o;
         o.trunc = 0;
+        // the step's uniform draw first (see sample_uniform)
+        const float u_draw = sample_uniform(a.env.seed, a.env.env_base + nn, a.sample_step0 + (uint64_t)t);
         // ---- backbone(s) + heads (src/ppo.py:126-145, :174-182)
         float out[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!(a.ablate & 1)) {
+        if (!(ABLATE(a) & 1)) {
             if (JOINT) {
                 net.template forward<true, true, false>(obs, out);
             } else {
@@ -572,14 +582,14 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 
         int action;
         float logp;
-        if (!(a.ablate & 4)) {
-            categorical_sample(lg, A, a.env.seed, a.env.env_base + nn, a.sample_step0 + (uint64_t)t, action, logp);
+        if (!(ABLATE(a) & 4)) {
+            categorical_from_uniform(lg, A, u_draw, action, logp);
         } else {
             action = lg[0] > lg[1]; logp = lg[0];
         }
 
         if (live) {
-            if (!(a.ablate & 2)) {
+            if (!(ABLATE(a) & 2)) {
                 env_transition<Env, DRAWS>(e, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead);
             } else {
 #pragma unroll

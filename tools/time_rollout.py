@@ -1,4 +1,5 @@
-"""Time the whole-rollout kernel alone (events around ve.rollout's kernel via rocprof is better; this
+"""PPO_ROLLOUT_ABLATE=<bits> needs a library built with -DPPO_ROLLOUT_ABLATE_BUILD (the switches are
+compiled out of the shipped kernel).  Time the whole-rollout kernel alone (events around ve.rollout's kernel via rocprof is better; this
 uses wall time over several rollouts with the stats disabled)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
