@@ -119,13 +119,12 @@ def main():
                 ev_dense = ve._ev_dense
             else:
                 ev_dense = ppo._scatter_end_values(ve, agent.get_values(ve.end_states))
-            record = record and len(gae_events) < 256   # ppo_prof_* has 256 slots
-            if record:
-                # hipExtLaunchKernelGGL start/stop events on the GAE dispatch itself (ppo_prof_* in
-                # csrc/gae.hip); read back after the timed region.  Agrees with rocprofv3 --kernel-trace.
-                slot = len(gae_events)
-                _lib.check(lib.ppo_prof_arm(slot), "ppo_prof_arm")
-            adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95)
+            record = record and len(gae_events) < 256   # the timed entry has 256 event slots
+            # hipExtLaunchKernelGGL start/stop events on the GAE dispatch itself (ppo_gae_dense_timed in
+            # csrc/gae.hip); read back after the timed region.  Agrees with rocprofv3 --kernel-trace.
+            slot = len(gae_events) if record else None
+            adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95,
+                                prof_slot=slot)
             if record:
                 gae_events.append(slot)
         return adv

@@ -17,8 +17,13 @@
  *     for rejected arguments; nothing has been launched in that case).
  *   - Matrices are row-major [T, N]: element (t, n) at t*N + n  (the layout of the
  *     reference's rollout buffers, src/ppo.py:309-315).
- *   - Re-entrant; no global state.  One host thread per device (the reference is
- *     single-threaded, so no concurrency contract is inherited).
+ *   - The entry points declared here keep no state between calls: what a call does depends on
+ *     its arguments only (no environment variables, no mode switches).  One host thread per
+ *     device (the reference is single-threaded, so no concurrency contract is inherited).
+ *     Exceptions, both stated where they are declared: ppo_gae_ragged_noalloc works in a
+ *     per-device scratch array inside the library, and the private bench hooks listed in
+ *     INTEGRATION.md (not declared here) keep process-wide HIP event slots and are for one
+ *     bench thread only.
  */
 #ifndef PPO_AMD_H
 #define PPO_AMD_H
@@ -155,7 +160,9 @@ int ppo_loss_fwd_bwd(const float *x, const float *old_lp, const float *new_v,
  * in what Agent.get_actions_and_values does with torch.distributions.Categorical on the update
  * path (src/ppo.py:186-189 logits -> distribution, :212 log_prob(actions), :214 entropy().mean())
  * and the ratio at :595, so log-softmax / probs / entropy tensors are never materialised.
- *   logits  [B, num_actions] f32 row-major, 2 <= num_actions <= 8;  actions [B] i32
+ *   logits  [B, num_actions] f32 row-major, 2 <= num_actions <= 8;  actions [B] i32 in
+ *           [0, num_actions): an action outside that range (torch raises) turns the four losses,
+ *           and that sample's gradients, into NaN
  *   out5    device f32[5] = policy_loss, value_loss, clip_frac, kl_div, mean entropy
  *   g_logits_pl  [B, num_actions]  d policy_loss / d logits   (NULL to skip)
  *   g_logits_ent [B, num_actions]  d mean-entropy / d logits  (NULL to skip)

@@ -36,12 +36,13 @@ SIGNATURES = {
     "ppo_rollout_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
-# tuning hook, deliberately not in the public header
+# tuning / test / bench hooks, deliberately not in the public header (listed in INTEGRATION.md)
 _PRIVATE = {
     "ppo_gae_dense_variant": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_stream_ceiling": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
-    "ppo_rollout_wave_envs": (_i, [_i]),
-    "ppo_prof_arm": (_i, [_i]),
+    "ppo_rollout_fused_ex": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_gae_dense_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_prof_elapsed_us": (_i, [_i, C.POINTER(C.c_float)]),
 }
 

@@ -20,14 +20,14 @@
 
 namespace {
 
-// Bench-only kernel timing (private symbols ppo_prof_*; not part of include/ppo_amd.h): an armed
-// slot makes the NEXT GAE launch go through hipExtLaunchKernelGGL with a start/stop event pair,
+// Bench-only kernel timing (private symbols ppo_gae_dense_timed / ppo_prof_elapsed_us; not part of
+// include/ppo_amd.h): a timed launch goes through hipExtLaunchKernelGGL with a start/stop event pair,
 // which timestamps the dispatch packet itself.  A plain hipEventRecord pair around the launch
-// also times two barrier packets (+25..50 us on this stack), rocprofv3 agrees with this form.
+// also times two barrier packets (+25..50 us on this stack); rocprofv3 agrees with this form.
+// The event slots are the library's only process-wide state: one bench thread, not thread-safe.
 constexpr int PROF_SLOTS = 256;
 hipEvent_t g_prof_start[PROF_SLOTS], g_prof_stop[PROF_SLOTS];
 bool g_prof_have[PROF_SLOTS];
-int g_prof_armed = -1;
 
 
 template <int VEC> struct VecT;
@@ -296,15 +296,13 @@ __global__ void __launch_bounds__(256) k_gae_sparse(GaeArgs a)
     }
 }
 
-template <int VEC, int U, bool NT = false> int launch_gae_sparse(const GaeArgs &a, hipStream_t s)
+template <int VEC, int U, bool NT = false> int launch_gae_sparse(const GaeArgs &a, hipStream_t s, int slot = -1)
 {
     const long threads = a.N / VEC;
     const long waves = (threads + 63) / 64;
     const int block = waves <= 2048 ? 64 : 256;
     const long grid = (threads + block - 1) / block;
-    if (g_prof_armed >= 0) {
-        const int slot = g_prof_armed;
-        g_prof_armed = -1;
+    if (slot >= 0) {
         hipExtLaunchKernelGGL((k_gae_sparse<VEC, U, NT>), dim3((unsigned)grid), dim3(block), 0, s, g_prof_start[slot],
                               g_prof_stop[slot], 0, a);
         return ppo_launch_status();
@@ -411,15 +409,16 @@ template <int VEC, int U, bool DENSE_EV> int launch_gae(const GaeArgs &a, hipStr
 // buffer, 2-7 fetch it only where a truncation is flagged; 6-7 use non-temporal accesses (measured
 // inside bench.py: <2,8> 34.0 us, <2,8,nt> 39.5, <1,8> 35.2, <1,8,nt> 33.5 -- no clear win, and the
 // <2,8> form is sensitive to how the compiler schedules its loads, so its source is left as it is).
-int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s)
+int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s, int slot = -1)
 {
+    if (slot >= 0 && variant != 3 && variant != 5) return (int)hipErrorInvalidValue;   // timed: the shipped forms only
     switch (variant) {
     case 0: return launch_gae<1, 8, true>(a, s);
     case 1: return launch_gae<2, 4, true>(a, s);
     case 2: return launch_gae_sparse<1, 4>(a, s);
-    case 3: return launch_gae_sparse<1, 8>(a, s);
+    case 3: return launch_gae_sparse<1, 8>(a, s, slot);
     case 4: return launch_gae_sparse<2, 4>(a, s);
-    case 5: return launch_gae_sparse<2, 8>(a, s);
+    case 5: return launch_gae_sparse<2, 8>(a, s, slot);
     case 6: return launch_gae_sparse<2, 8, true>(a, s);
     case 7: return launch_gae_sparse<1, 8, true>(a, s);
     default: return (int)hipErrorInvalidValue;
@@ -432,10 +431,9 @@ int variant_vec(int variant) { return (variant == 1 || variant == 4 || variant =
 
 extern "C" {
 
-// Tuning hook (not part of the public header): pick a (VEC, U) instantiation explicitly.
-int ppo_gae_dense_variant(const float *rewards, const float *values, const float *end_value_dense,
-                          const int *done, const int *trunc, double gamma, double lam, float *adv,
-                          float *ret, int T, int N, int variant, void *stream)
+static int gae_dense_launch(const float *rewards, const float *values, const float *end_value_dense,
+                            const int *done, const int *trunc, double gamma, double lam, float *adv,
+                            float *ret, int T, int N, int variant, int slot, void *stream)
 {
     PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
     PPO_REQUIRE(T >= 0 && N >= 0);
@@ -448,7 +446,27 @@ int ppo_gae_dense_variant(const float *rewards, const float *values, const float
                 (!ret || ppo_aligned(ret, al)));
     GaeArgs a{rewards, values, end_value_dense, done, trunc, adv, ret, nullptr, 0, nullptr,
               (float)gamma, (float)(gamma * lam), T, N};
-    return launch_gae_dense_variant(a, variant, (hipStream_t)stream);
+    return launch_gae_dense_variant(a, variant, (hipStream_t)stream, slot);
+}
+
+// Measured on MI355X at T=128, N=65536: sparse end values, two columns per lane,
+// 8-row blocks is the fastest form; it needs an even N and 8-byte aligned bases.
+static int gae_default_variant(const float *rewards, const float *values, const float *end_value_dense,
+                               const int *done, const int *trunc, const float *adv, const float *ret, int N)
+{
+    const bool vec2 = (N % 2 == 0) && ppo_aligned(rewards, 8) && ppo_aligned(values, 8) &&
+                      ppo_aligned(end_value_dense, 8) && ppo_aligned(done, 8) && ppo_aligned(trunc, 8) &&
+                      ppo_aligned(adv, 8) && (!ret || ppo_aligned(ret, 8));
+    return vec2 ? 5 : 3;
+}
+
+// Tuning hook (not part of the public header): pick a (VEC, U) instantiation explicitly.
+int ppo_gae_dense_variant(const float *rewards, const float *values, const float *end_value_dense,
+                          const int *done, const int *trunc, double gamma, double lam, float *adv,
+                          float *ret, int T, int N, int variant, void *stream)
+{
+    return gae_dense_launch(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N, variant, -1,
+                            stream);
 }
 
 int ppo_gae_dense(const float *rewards, const float *values, const float *end_value_dense,
@@ -456,27 +474,26 @@ int ppo_gae_dense(const float *rewards, const float *values, const float *end_va
                   float *ret, int T, int N, void *stream)
 {
     PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
-    // Measured on MI355X at T=128, N=65536: sparse end values, two columns per lane,
-    // 8-row blocks is the fastest form; it needs an even N and 8-byte aligned bases.
-    const bool vec2 = (N % 2 == 0) && ppo_aligned(rewards, 8) && ppo_aligned(values, 8) &&
-                      ppo_aligned(end_value_dense, 8) && ppo_aligned(done, 8) && ppo_aligned(trunc, 8) &&
-                      ppo_aligned(adv, 8) && (!ret || ppo_aligned(ret, 8));
-    return ppo_gae_dense_variant(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
-                                 vec2 ? 5 : 3, stream);
+    return gae_dense_launch(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
+                            gae_default_variant(rewards, values, end_value_dense, done, trunc, adv, ret, N), -1, stream);
 }
 
-// Bench-only: time the next GAE launch into `slot` / read a finished slot back (waits for it).
-int ppo_prof_arm(int slot)
+// Bench-only (private): ppo_gae_dense whose dispatch is timed into event slot `slot`; read the slot
+// back with ppo_prof_elapsed_us (which waits for it).  Single bench thread; slots are process-wide.
+int ppo_gae_dense_timed(const float *rewards, const float *values, const float *end_value_dense,
+                        const int *done, const int *trunc, double gamma, double lam, float *adv,
+                        float *ret, int T, int N, int slot, void *stream)
 {
-    PPO_REQUIRE(slot >= 0 && slot < PROF_SLOTS);
+    PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
+    PPO_REQUIRE(slot >= 0 && slot < PROF_SLOTS && T > 0 && N > 0);
     if (!g_prof_have[slot]) {
         hipError_t e = hipEventCreate(&g_prof_start[slot]);
         if (e == hipSuccess) e = hipEventCreate(&g_prof_stop[slot]);
         if (e != hipSuccess) return (int)e;
         g_prof_have[slot] = true;
     }
-    g_prof_armed = slot;
-    return 0;
+    return gae_dense_launch(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
+                            gae_default_variant(rewards, values, end_value_dense, done, trunc, adv, ret, N), slot, stream);
 }
 
 int ppo_prof_elapsed_us(int slot, float *us)

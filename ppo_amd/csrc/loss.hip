@@ -268,6 +268,9 @@ template <int A> __global__ void __launch_bounds__(LOSS_BLOCK) k_loss_logits_par
             H -= lp[k] * pr[k];                         // Categorical.entropy
             if (k == act) new_lp = lp[k];               // Categorical.log_prob
         }
+        // an action outside [0, A) has no log-prob: torch's Categorical.log_prob raises; here the
+        // sample poisons every output (NaN losses and gradients) instead of passing as new_lp = 0
+        if ((unsigned)act >= (unsigned)A) new_lp = __builtin_nanf("");
         const float rho = expf(new_lp - a.old_lp[i]);   // :595
         const SampleOut o = loss_sample(c, rho, a.adv[i], a.old_v[i], a.new_v[i]);
         const float g_lp = o.g_rho * rho;               // d policy_loss / d new_lp

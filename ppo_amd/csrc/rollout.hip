@@ -34,7 +34,9 @@
 // the f32 form is bound by its 144 x 64 MFMA cycles, which do not overlap with the wave's VALU
 // work).  HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done, trunc).
 #include "env_core.h"
+#ifdef PPO_ROLLOUT_ABLATE_BUILD
 #include <cstdlib>
+#endif
 
 using namespace ppo_env;
 
@@ -646,11 +648,10 @@ template <class Env, class Net> void launch_net(const RolloutArgs &a, unsigned g
 
 // Envs per wave for the f16-split nets: 64, or 32 when the batch is too small to give every SIMD of
 // the chip (256 CUs x 4) a wave of 64 -- twice the waves, each with half the network work.
-// g_wave_envs: 0 = choose by N, 32 / 64 = forced (tests and tuning; ppo_rollout_wave_envs below).
-int g_wave_envs = 0;
+// wave_envs: 0 = choose by N, 32 / 64 = forced (tests and tuning, through ppo_rollout_fused_ex).
 constexpr int HALF_WAVE_MAX_ENVS = 32768;
 
-template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, int net_mode, hipStream_t s)
+template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, int net_mode, int wave_envs, hipStream_t s)
 {
     constexpr int OBS = Env::OBS;
     const auto grid_for = [&](int wave_envs) {
@@ -661,7 +662,7 @@ template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, 
         if (joint) launch_net<Env, NetF32<OBS, A, true>>(a, grid_for(64), s);
         else launch_net<Env, NetF32<OBS, A, false>>(a, grid_for(64), s);
     } else {
-        const bool half_waves = g_wave_envs ? g_wave_envs == 32 : a.env.N <= HALF_WAVE_MAX_ENVS;
+        const bool half_waves = wave_envs ? wave_envs == 32 : a.env.N <= HALF_WAVE_MAX_ENVS;
         if (half_waves) {
             if (joint) launch_net<Env, NetF16<OBS, A, true, 1>>(a, grid_for(32), s);
             else launch_net<Env, NetF16<OBS, A, false, 1>>(a, grid_for(32), s);
@@ -677,14 +678,6 @@ template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, 
 
 extern "C" {
 
-// tuning / test hook, not in the public header: 0 = choose by N (default), 32 or 64 = forced
-int ppo_rollout_wave_envs(int wave_envs)
-{
-    PPO_REQUIRE(wave_envs == 0 || wave_envs == 32 || wave_envs == 64);
-    g_wave_envs = wave_envs;
-    return 0;
-}
-
 size_t ppo_rollout_param_floats(int kind, int joint, int net_mode)
 {
     const int obs = ppo_env_obs_dim(kind);
@@ -693,13 +686,16 @@ size_t ppo_rollout_param_floats(int kind, int joint, int net_mode)
     return bb * (joint ? 1 : 2) + (size_t)HEAD_FLOATS;
 }
 
-int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len, uint32_t *episode,
-                      const double *reset_draw, uint64_t seed, uint64_t env_base, const float *params,
-                      int joint, int net_mode, uint64_t sample_step0, float *obs_io, float *states, int *actions,
-                      float *log_probs, float *values, float *rewards, int *done, int *trunc, float *term_obs,
-                      float *ev_dense, double *reward_sum, float *ret_ring, int *len_ring, int *ring_cnt, int ring,
-                      int N, int T, void *stream)
+// Private form (tests and tuning; not in the public header): ppo_rollout_fused with the number of
+// envs per wave of the f16-split kernels forced to 32 or 64 (0 = chosen by N, what the public entry does).
+int ppo_rollout_fused_ex(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len, uint32_t *episode,
+                         const double *reset_draw, uint64_t seed, uint64_t env_base, const float *params,
+                         int joint, int net_mode, uint64_t sample_step0, float *obs_io, float *states, int *actions,
+                         float *log_probs, float *values, float *rewards, int *done, int *trunc, float *term_obs,
+                         float *ev_dense, double *reward_sum, float *ret_ring, int *len_ring, int *ring_cnt, int ring,
+                         int N, int T, int wave_envs, void *stream)
 {
+    PPO_REQUIRE(wave_envs == 0 || wave_envs == 32 || wave_envs == 64);
     PPO_REQUIRE(kind == PPO_ENV_CARTPOLE || kind == PPO_ENV_ACROBOT);
     PPO_REQUIRE(!reward_sum || ppo_aligned(reward_sum, 8));
     PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT);
@@ -721,11 +717,25 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
     a.params = params; a.sample_step0 = sample_step0; a.obs_io = obs_io; a.states = states; a.actions = actions;
     a.log_probs = log_probs; a.values = values; a.rewards = rewards; a.done = done; a.trunc = trunc;
     a.term_obs = term_obs; a.ev_dense = ev_dense; a.reward_sum = reward_sum; a.T = T;
-    const char *abl = getenv("PPO_ROLLOUT_ABLATE");
-    a.ablate = abl ? atoi(abl) : 0;
+#ifdef PPO_ROLLOUT_ABLATE_BUILD
+    static const int ablate_env = [] { const char *e = getenv("PPO_ROLLOUT_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = ablate_env;                          // diagnostic builds only; read once
+#endif
     hipStream_t s = (hipStream_t)stream;
-    if (kind == PPO_ENV_CARTPOLE) return launch_rollout<CartPole, 2>(a, joint, net_mode, s);
-    return launch_rollout<Acrobot, 3>(a, joint, net_mode, s);
+    if (kind == PPO_ENV_CARTPOLE) return launch_rollout<CartPole, 2>(a, joint, net_mode, wave_envs, s);
+    return launch_rollout<Acrobot, 3>(a, joint, net_mode, wave_envs, s);
+}
+
+int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len, uint32_t *episode,
+                      const double *reset_draw, uint64_t seed, uint64_t env_base, const float *params,
+                      int joint, int net_mode, uint64_t sample_step0, float *obs_io, float *states, int *actions,
+                      float *log_probs, float *values, float *rewards, int *done, int *trunc, float *term_obs,
+                      float *ev_dense, double *reward_sum, float *ret_ring, int *len_ring, int *ring_cnt, int ring,
+                      int N, int T, void *stream)
+{
+    return ppo_rollout_fused_ex(kind, state, elapsed, ep_ret, ep_len, episode, reset_draw, seed, env_base, params, joint,
+                                net_mode, sample_step0, obs_io, states, actions, log_probs, values, rewards, done, trunc,
+                                term_obs, ev_dense, reward_sum, ret_ring, len_ring, ring_cnt, ring, N, T, 0, stream);
 }
 
 }  // extern "C"

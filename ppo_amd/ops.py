@@ -49,8 +49,9 @@ def _workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- GAE
 def gae_dense(rewards, values, end_value_dense, done_flags, trunc_flags, gamma, lam,
-              want_returns=False, out=None, variant=None):
-    """ppo_gae_dense: replaces reference src/ppo.py:452-488 with dense bootstrap values."""
+              want_returns=False, out=None, variant=None, prof_slot=None):
+    """ppo_gae_dense: replaces reference src/ppo.py:452-488 with dense bootstrap values.
+    prof_slot (bench only): time the dispatch into that event slot (ppo_gae_dense_timed)."""
     lib = _lib.load()
     src_dev = rewards.device
     r, v, ev = _dev(rewards, torch.float32), _dev(values, torch.float32), _dev(end_value_dense, torch.float32)
@@ -61,7 +62,10 @@ def gae_dense(rewards, values, end_value_dense, done_flags, trunc_flags, gamma, 
     ret = torch.empty((T, N), dtype=torch.float32, device=r.device) if want_returns else None
     if variant is None and _GAE_VARIANT is not None:
         variant = _GAE_VARIANT
-    if variant is None:
+    if prof_slot is not None:
+        rc = lib.ppo_gae_dense_timed(_ptr(r), _ptr(v), _ptr(ev), _ptr(d), _ptr(tr), float(gamma), float(lam),
+                                     _ptr(adv), _ptr(ret), T, N, int(prof_slot), _stream())
+    elif variant is None:
         rc = lib.ppo_gae_dense(_ptr(r), _ptr(v), _ptr(ev), _ptr(d), _ptr(tr), float(gamma), float(lam),
                                _ptr(adv), _ptr(ret), T, N, _stream())
     else:
@@ -547,16 +551,21 @@ def pack_dense_agent(agent, net_mode: int = NET_F32) -> torch.Tensor:
 
 
 def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, log_probs, values, rewards, done,
-                  trunc, term_obs, ev_dense, T, net_mode: int = NET_F32, reward_sum=None):
-    """ppo_rollout_fused over a ppo_amd.envs.DeviceEnvBatch; every tensor is written in place."""
+                  trunc, term_obs, ev_dense, T, net_mode: int = NET_F32, reward_sum=None, wave_envs: int = 0):
+    """ppo_rollout_fused over a ppo_amd.envs.DeviceEnvBatch; every tensor is written in place.
+    wave_envs != 0 (tests / tuning) forces 32 or 64 envs per wave through the private _ex entry."""
     lib = _lib.load()
     need = lib.ppo_rollout_param_floats(batch.kind, int(bool(joint)), int(net_mode))
     assert params.numel() == need and params.dtype == torch.float32 and params.is_cuda, (params.numel(), need)
-    rc = lib.ppo_rollout_fused(
+    args = (
         batch.kind, batch.state.data_ptr(), batch.elapsed.data_ptr(), batch.ep_ret.data_ptr(),
         batch.ep_len.data_ptr(), batch.episode.data_ptr(), None, batch.seed, batch.env_base, params.data_ptr(),
         int(bool(joint)), int(net_mode), int(sample_step0), obs_io.data_ptr(), states.data_ptr(), actions.data_ptr(),
         log_probs.data_ptr(), values.data_ptr(), rewards.data_ptr(), done.data_ptr(), trunc.data_ptr(),
         term_obs.data_ptr(), _ptr(ev_dense), _ptr(reward_sum), batch.ret_ring.data_ptr(), batch.len_ring.data_ptr(), batch.ring_cnt.data_ptr(),
-        batch.ring, batch.num_envs, int(T), _stream())
+        batch.ring, batch.num_envs, int(T))
+    if wave_envs:
+        rc = lib.ppo_rollout_fused_ex(*args, int(wave_envs), _stream())
+    else:
+        rc = lib.ppo_rollout_fused(*args, _stream())
     _lib.check(rc, "ppo_rollout_fused")

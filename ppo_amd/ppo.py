@@ -206,6 +206,7 @@ class SyncVecEnv:
         # MFMA products (ops.NET_F32), or f16 MFMAs on two-piece splits (ops.NET_F16_SPLIT, ~1.5x faster,
         # 22 bits per operand); PPO_AMD_NET=f32 selects the former
         self.net_mode = ops.NET_F32 if os.environ.get("PPO_AMD_NET", "f16_split") == "f32" else ops.NET_F16_SPLIT
+        self.wave_envs = 0           # tests / tuning: force 32 or 64 envs per wave (0 = the library chooses by N)
         self._rollouts = 0
 
         first = env_fn()
@@ -314,7 +315,7 @@ class SyncVecEnv:
             ops.rollout_fused(b, self._packed_params(), self.agent.joint_net, self._rollouts * T, carry,
                               self.states, self.actions, self.log_probs, self.values, self.rewards,
                               self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T,
-                              net_mode=self.net_mode, reward_sum=rsum)
+                              net_mode=self.net_mode, reward_sum=rsum, wave_envs=self.wave_envs)
             self._ev_ready = True                      # bootstrap values already written by the kernel
         else:
             carry = torch.empty((N, b.obs_dim), dtype=torch.float32, device=kdev)

@@ -27,6 +27,22 @@ def test_header_symbols_all_exported():
     assert sorted(_lib.SIGNATURES) == syms
 
 
+def test_every_exported_symbol_is_declared_or_listed_private():
+    """nm -D: the library exports nothing beyond include/ppo_amd.h and the private hooks that
+    ppo_amd/_lib.py (_PRIVATE) and INTEGRATION.md list."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("ppo_")
+                       and ln.split()[-2] in ("T", "t", "W")})
+    known = set(declared_symbols()) | set(_lib._PRIVATE)
+    assert exported, "nm found no ppo_* symbols"
+    assert set(exported) <= known, f"exported but neither declared nor private: {sorted(set(exported) - known)}"
+    assert known <= set(exported), f"declared or listed but not exported: {sorted(known - set(exported))}"
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in _lib._PRIVATE:
+        assert name in integration, f"private hook {name} is not documented in INTEGRATION.md"
+
+
 def test_abi_version_and_obs_dim():
     lib = _lib.load()
     assert lib.ppo_abi_version() == 1

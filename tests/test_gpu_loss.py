@@ -245,3 +245,24 @@ def test_logits_rejects_bad_arguments():
     with pytest.raises(_lib.PpoAmdError):   # 9 actions: outside the compiled 2..8 range
         ops.loss_logits_fwd_bwd(torch.zeros(B, 9, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda"),
                                 z, z, z, z, 0.2, 0, 0)
+
+
+def test_logits_out_of_range_action_poisons_the_losses():
+    """torch's Categorical.log_prob raises on an action outside [0, A) (reference src/ppo.py:212); the
+    kernel must not pass it as log-prob 0: the losses and that sample's gradients become NaN, the
+    other samples' gradients stay finite."""
+    from ppo_amd import ops
+    B, A = 300, 3
+    g = torch.Generator(device="cuda").manual_seed(1)
+    logits = torch.randn(B, A, device="cuda", generator=g)
+    actions = torch.randint(0, A, (B,), device="cuda", dtype=torch.int32, generator=g)
+    z = torch.randn(B, device="cuda", generator=g)
+    for bad in (A, -1, 77):
+        act = actions.clone()
+        act[17] = bad
+        out5, gpl, gent, gv = ops.loss_logits_fwd_bwd(logits, act, -z.abs(), z, z * 0.5, z + 1.0, 0.2, 1, 1)
+        assert bool(torch.isnan(out5[0])) and bool(torch.isnan(out5[3]))
+        assert bool(torch.isnan(gpl[17]).all())
+        keep = torch.ones(B, dtype=torch.bool, device="cuda")
+        keep[17] = False
+        assert bool(torch.isfinite(gpl[keep]).all()) and bool(torch.isfinite(gv[keep]).all())

@@ -68,9 +68,6 @@ def test_device_rollout_matches_serial_reference_loop(kind, joint, whole, reques
     torch.manual_seed(0)
     f16 = whole in ("f16_split", "f16_split_wave64")
     N, T, seed = (70 if f16 else 64), 96, 2024   # 70: a partial wave (tail lanes shadow env N-1)
-    # small batches run 32 envs per wave (lanes 0-31); force the 64-env form for the last case
-    _lib.load().ppo_rollout_wave_envs(64 if whole == "f16_split_wave64" else 0)
-    request.addfinalizer(lambda: _lib.load().ppo_rollout_wave_envs(0))
     probe = DeviceEnv(kind)
     agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=joint, device="cuda")
     with torch.no_grad():  # away from the near-uniform init so that log-probs / values are non-trivial
@@ -81,6 +78,8 @@ def test_device_rollout_matches_serial_reference_loop(kind, joint, whole, reques
     from ppo_amd import ops
     ve.fused_rollout = whole is not None
     ve.net_mode = ops.NET_F32 if whole == "f32" else ops.NET_F16_SPLIT
+    # small batches run 32 envs per wave (lanes 0-31); force the 64-env form for the last case
+    ve.wave_envs = 64 if whole == "f16_split_wave64" else 0
 
     ora = cref.BatchEnv(kind, N, seed=seed)
     t_states = torch.from_numpy(ora.reset())
@@ -315,8 +314,6 @@ def test_fused_rollout_bootstraps_time_limit_truncations(kind, joint, wave_envs,
     the PyTorch critic on the recorded terminal observations."""
     from ppo_amd import Agent, SyncVecEnv
     from ppo_amd.envs import DeviceEnv
-    request.addfinalizer(lambda: _lib.load().ppo_rollout_wave_envs(0))
-    _lib.load().ppo_rollout_wave_envs(wave_envs)
     torch.manual_seed(5)
     N, T = 200, 64
     probe = DeviceEnv(kind)
@@ -324,6 +321,7 @@ def test_fused_rollout_bootstraps_time_limit_truncations(kind, joint, wave_envs,
     with torch.no_grad():
         agent.critic.bias.fill_(0.7)
     ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=9), N, T, 0, 0.0, agent, seed=9)
+    ve.wave_envs = wave_envs
     rng = np.random.default_rng(0)
     left = rng.integers(1, T - 1, N).astype(np.int32)          # steps until the time limit, per env
     ve.batch.elapsed.copy_(torch.from_numpy(500 - left))
@@ -381,7 +379,6 @@ def test_rollout_is_bit_identical_for_both_wave_widths(kind, joint, request):
     rollout buffer is bit-identical."""
     from ppo_amd import Agent, SyncVecEnv
     from ppo_amd.envs import DeviceEnv
-    request.addfinalizer(lambda: _lib.load().ppo_rollout_wave_envs(0))
     torch.manual_seed(3)
     probe = DeviceEnv(kind)
     agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
@@ -389,8 +386,8 @@ def test_rollout_is_bit_identical_for_both_wave_widths(kind, joint, request):
         agent.policy.weight.mul_(40.0)
     got = {}
     for width in (32, 64):
-        _lib.load().ppo_rollout_wave_envs(width)
         ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=11), 333, 64, 0, 0.0, agent, seed=11)
+        ve.wave_envs = width
         ve.rollout(); ve.rollout()
         got[width] = [getattr(ve, k).detach().clone() for k in
                       ("states", "actions", "log_probs", "values", "rewards", "done_flags", "trunc_flags", "t_states")]

@@ -14,7 +14,7 @@ probe = DeviceEnv(kind)
 agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
 ve = SyncVecEnv(lambda: DeviceEnv(kind), N, T, 0, 0.0, agent, seed=0)
 ve._device_episode_stats = lambda: None
-if os.environ.get('PPO_WAVE_ENVS'): ops._lib.load().ppo_rollout_wave_envs(int(os.environ['PPO_WAVE_ENVS']))   # 32 / 64: forced
+ve.wave_envs = int(os.environ.get('PPO_WAVE_ENVS', '0'))   # 32 / 64: forced
 if os.environ.get('PPO_SPREAD_ELAPSED'):   # TimeLimit counters spread over [0, 500): the steady state of long episodes
     ve.batch.elapsed.copy_(torch.randint(0, 500, (N,), device='cuda', dtype=torch.int32))
 for _ in range(2): ve.rollout()
