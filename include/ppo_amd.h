@@ -20,10 +20,8 @@
  *   - The entry points declared here keep no state between calls: what a call does depends on
  *     its arguments only (no environment variables, no mode switches).  One host thread per
  *     device (the reference is single-threaded, so no concurrency contract is inherited).
- *     Exceptions, both stated where they are declared: ppo_gae_ragged_noalloc works in a
- *     per-device scratch array inside the library, and the private bench hooks listed in
- *     INTEGRATION.md (not declared here) keep process-wide HIP event slots and are for one
- *     bench thread only.
+ *     Exception: the private bench hooks listed in INTEGRATION.md (not declared here) keep
+ *     process-wide HIP event slots and are for one bench thread only.
  */
 #ifndef PPO_AMD_H
 #define PPO_AMD_H
@@ -43,7 +41,9 @@ extern "C" {
 /* How ppo_rollout_fused multiplies inside the policy / value network (the result is f32 either way) */
 #define PPO_NET_F32 0        /* v_mfma_f32_32x32x2_f32: every product an exact f32 FMA */
 #define PPO_NET_F16_SPLIT 1  /* v_mfma_f32_32x32x16_f16 on two-piece f16 splits of both operands
-                                (22 significant bits per operand, f32 accumulate): ~1.9x faster */
+                                (22 significant bits per operand, f32 accumulate): ~1.9x faster.
+                                As accurate as f32 unless the backbone weights are tiny: see
+                                split_margin of ppo_rollout_pack_params */
 
 int ppo_abi_version(void);
 
@@ -216,8 +216,32 @@ int ppo_categorical_sample(const float *logits, int A, uint64_t seed, uint64_t e
                            uint64_t step, int *action, float *logp, int N, void *stream);
 
 /* Number of floats in the packed dense-network parameter buffer ppo_rollout_fused reads
- * (layout in ppo_amd/csrc/rollout.hip; built by ppo_amd.ops.pack_dense_agent). */
+ * (layout in ppo_amd/csrc/rollout.hip; built by ppo_rollout_pack_params). */
 size_t ppo_rollout_param_floats(int kind, int joint, int net_mode);
+
+/*
+ * Pack the dense policy / value network of the reference's Agent (src/ppo.py:124-145: pi_backbone
+ * Linear(obs,64)-tanh-Linear(64,64)-tanh, optional va_backbone of the same shape, policy head
+ * Linear(64,A), critic head Linear(64,1)) into the buffer ppo_rollout_fused reads: one launch,
+ * straight from the nn.Linear tensors (weights row-major [out, in], f32), so that the rollout that
+ * follows an optimiser step never waits for host work.
+ *   kind       fixes obs (4 / 6) and A (2 / 3);  joint != 0: va_* are ignored (may be NULL)
+ *   net_mode   PPO_NET_F32 or PPO_NET_F16_SPLIT (the layout differs)
+ *   params_out ppo_rollout_param_floats(kind, joint, net_mode) floats
+ *   split_margin  device f32[1] or NULL: how far this parameter set is from the point where
+ *              PPO_NET_F16_SPLIT loses accuracy against f32.  The split's low piece of a value below
+ *              2^-3 is an f16 subnormal (absolute error 2^-25); the margin is the minimum, over the
+ *              backbone weight tensors, of 8 sum|w'| / #{|w'| < 2^-3} with w' = 2 log2(e) w, i.e. the
+ *              ratio of the mode's inherent 2^-22 relative error to that floor for inputs of equal
+ *              size.  Use the split kernels for margins >= 4 (ppo_amd.ops.SPLIT_MARGIN_MIN; a
+ *              default-initialised or trained network sits at 15-20), PPO_NET_F32 below.
+ */
+int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w1, const float *pi_b1,
+                            const float *pi_w2, const float *pi_b2, const float *va_w1,
+                            const float *va_b1, const float *va_w2, const float *va_b2,
+                            const float *policy_w, const float *policy_b, const float *critic_w,
+                            const float *critic_b, float *params_out, float *split_margin,
+                            void *stream);
 
 /*
  * A whole T-step rollout of N envs in ONE launch: per time step the dense 64-64 tanh policy /

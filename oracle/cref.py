@@ -142,6 +142,29 @@ def reset_uniform4(seed, env_id, episode):
     return u
 
 
+def sample_uniform(seed, env_base, step, N):
+    """The [0,1) draws behind the sampled actions of policy step `step` for envs env_base..env_base+N-1."""
+    u = np.empty((N,), np.float32)
+    lib().oracle_sample_uniform_batch(C.c_uint64(seed), C.c_uint64(env_base), C.c_uint64(step), _p(u, C.c_float),
+                                      C.c_int(N))
+    return u
+
+
+def categorical_check(logits, u, actions, margin=1e-5):
+    """Inverse-CDF sampling check in float64: returns (mismatches, ambiguous) -- the number of rows whose
+    action differs from the first k with u * sum < cdf_k although u * sum is further than `margin`
+    (relative to sum) from every CDF boundary, and the number of rows inside such a margin."""
+    lg = np.asarray(logits, np.float64)
+    e = np.exp(lg - lg.max(axis=1, keepdims=True))
+    cdf = np.cumsum(e, axis=1)
+    tot = cdf[:, -1]
+    target = np.asarray(u, np.float64) * tot
+    pick = np.minimum((target[:, None] >= cdf).sum(axis=1), lg.shape[1] - 1)
+    near = (np.abs(cdf[:, :-1] - target[:, None]) <= margin * tot[:, None]).any(axis=1)
+    bad = (pick != np.asarray(actions).reshape(-1)) & ~near
+    return int(bad.sum()), int(near.sum())
+
+
 KIND = {"cartpole": 0, "acrobot": 1}
 OBS_DIM = {0: 4, 1: 6}
 

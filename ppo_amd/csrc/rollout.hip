@@ -34,6 +34,7 @@
 // the f32 form is bound by its 144 x 64 MFMA cycles, which do not overlap with the wave's VALU
 // work).  HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done, trunc).
 #include "env_core.h"
+#include "net_layout.h"
 #ifdef PPO_ROLLOUT_ABLATE_BUILD
 #include <cstdlib>
 #endif
@@ -50,7 +51,7 @@ using namespace ppo_env;
 
 namespace {
 
-constexpr int H = 64;  // hidden width of the reference's dense net (src/ppo.py:127-129)
+using namespace ppo_net;   // H, ksteps, backbone_floats, HEAD_FLOATS, BB16_* (net_layout.h)
 
 struct RolloutArgs {
     EnvArgs env;             // state, counters, rings, reset stream (action/obs_out/... unused)
@@ -80,9 +81,7 @@ struct RolloutArgs {
 //   layer 1, s > 0  : W[32 o + (l & 31)][2 (s - 1) + (l >> 5)]     (inputs in natural order)
 //   layer 2, s > 0  : W[32 o + (l & 31)][unit(o_in, r_in, l >> 5)],  s = 1 + 16 o_in + r_in
 //   HL[j][o][r][l]  : Whead_j[unit(o, r, l >> 5)]
-__host__ __device__ constexpr int ksteps(int k_in) { return 1 + (k_in + 1) / 2; }
-__host__ __device__ constexpr int backbone_floats(int obs) { return (ksteps(obs) + ksteps(H)) * 2 * 64; }
-constexpr int HEAD_FLOATS = 4 * 2 * 16 * 64 + 4;
+// (ksteps, backbone_floats, HEAD_FLOATS, BB16_*: net_layout.h, shared with the pack kernel in pack.hip)
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -277,8 +276,6 @@ struct Frag16 {
     uint32_t w[4];
 };
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
-constexpr int BB16_W1 = 2 * 2 * 64 * 4, BB16_W2 = 4 * 2 * 2 * 64 * 4, BB16_B2 = 2 * 16 * 64;
-constexpr int BB16_WORDS = BB16_W1 + BB16_W2 + BB16_B2;
 
 __device__ __forceinline__ f32x16 mfma16(const Frag16 &a, const Frag16 &b, f32x16 c)
 {

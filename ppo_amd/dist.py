@@ -35,8 +35,8 @@ def init_from_env(backend: str | None = None) -> bool:
         return False
     if td.is_initialized():
         return True
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:  # PPO_AMD_DIST_BACKEND=gloo: rehearse several ranks on ONE GPU (RCCL wants a GPU per rank)
+        backend = os.environ.get("PPO_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -90,3 +90,13 @@ def mean_scalar(x: torch.Tensor) -> torch.Tensor:
     y = x.clone()
     td.all_reduce(y, op=td.ReduceOp.SUM)
     return y / world_size()
+
+
+def max_scalar(x: float) -> float:
+    """Max of a host float over ranks (the whole job is as slow as its slowest rank)."""
+    if not is_dist():
+        return x
+    dev = "cuda" if td.get_backend() == "nccl" else "cpu"
+    y = torch.tensor([x], dtype=torch.float64, device=dev)
+    td.all_reduce(y, op=td.ReduceOp.MAX)
+    return float(y.item())

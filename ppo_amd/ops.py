@@ -9,8 +9,6 @@ from __future__ import annotations
 
 import os
 
-import numpy as np
-
 import torch
 
 from . import _lib
@@ -307,247 +305,63 @@ def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int
 
 
 # --------------------------------------------------------------------------- fused rollout
-def _d_layout_unit(o, r, half):
-    """Hidden unit held by register r of output tile o in lane half `half` of the
-    v_mfma_f32_32x32x2_f32 D layout (rollout.hip: unit(o, r, h))."""
-    return 32 * o + (r & 3) + 8 * (r >> 2) + 4 * half
+NET_F32, NET_F16_SPLIT, NET_AUTO = 0, 1, 2   # include/ppo_amd.h: PPO_NET_F32, PPO_NET_F16_SPLIT; AUTO is resolved here
+# NET_AUTO: the split kernels run only if ppo_rollout_pack_params' split_margin of the parameter set is
+# at least this (pack.hip: >= 1 means the f16-subnormal floor of small weights is below the mode's
+# inherent 2^-22 relative error; the value is calibrated by tests/test_gpu_net_precision.py)
+SPLIT_MARGIN_MIN = 4.0
+_KIND_OF_OBS = {4: 0, 6: 1}
 
 
-def _mfma_frags(weight: torch.Tensor, bias: torch.Tensor, chained: bool = False) -> torch.Tensor:
-    """Linear(K -> 64) as v_mfma_f32_32x32x2_f32 A-operand fragments [1 + K/2, 2, 64]
-    (layout documented in ppo_amd/csrc/rollout.hip).  chained=True: K = 64 inputs arrive as the
-    previous layer's accumulator registers, i.e. k-step 1 + 16 o + r pairs the units
-    unit(o, r, 0) and unit(o, r, 1)."""
-    W = weight.detach().to(torch.float32)
-    K = W.shape[1]
-    if K % 2:
-        W = torch.cat([W, W.new_zeros(64, 1)], dim=1)
-        K += 1
-    dev = W.device
-    lane = torch.arange(64, device=dev)
-    half, l31 = lane >> 5, lane & 31
-    s = torch.arange(K // 2, device=dev)
-    if chained:
-        assert K == 64
-        o_in, r_in = s // 16, s % 16
-        col = _d_layout_unit(o_in[:, None], r_in[:, None], half[None, :])    # [32 k-steps, 64 lanes]
+def rollout_param_floats(kind: int, joint, net_mode: int) -> int:
+    return int(_lib.load().ppo_rollout_param_floats(int(kind), int(bool(joint)), int(net_mode)))
+
+
+def pack_dense_agent(agent, net_mode: int = NET_F32, out: torch.Tensor | None = None,
+                     margin_out: torch.Tensor | None = None) -> torch.Tensor:
+    """ppo_rollout_pack_params: the dense Agent's nn.Linear tensors -> the layout k_rollout reads, one
+    launch, no host work beyond the call.  net_mode is NET_F32 or NET_F16_SPLIT; margin_out (device
+    f32[1]) receives the split-mode margin of this parameter set."""
+    lib = _lib.load()
+    assert net_mode in (NET_F32, NET_F16_SPLIT)
+    pi = agent.pi_backbone
+    w1 = pi[0].weight
+    if not w1.is_cuda:
+        raise _lib.PpoAmdError("pack_dense_agent needs the agent on the HIP device; there is no CPU fallback")
+    kind = _KIND_OF_OBS[w1.shape[1]]
+    joint = bool(agent.joint_net)
+    tensors = [pi[0].weight, pi[0].bias, pi[2].weight, pi[2].bias]
+    if joint:
+        tensors += [None] * 4
     else:
-        col = 2 * s[:, None] + half[None, :]
-    frag = W.new_zeros(1 + K // 2, 2, 64)
-    for o in range(2):
-        frag[0, o] = torch.where(half == 0, bias.detach().to(torch.float32)[32 * o + l31], W.new_zeros(()))
-        frag[1:, o] = W[(32 * o + l31)[None, :], col]
-    return frag.reshape(-1)
+        va = agent.va_backbone
+        tensors += [va[0].weight, va[0].bias, va[2].weight, va[2].bias]
+    tensors += [agent.policy.weight, agent.policy.bias, agent.critic.weight, agent.critic.bias]
+    assert agent.policy.weight.shape[0] == (2 if kind == 0 else 3)
+    for t in tensors:
+        assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
+    n = rollout_param_floats(kind, joint, net_mode)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w1.device)
+    assert out.numel() == n and out.dtype == torch.float32 and out.is_cuda
+    rc = lib.ppo_rollout_pack_params(kind, int(joint), int(net_mode), *[_ptr(t) for t in tensors], _ptr(out),
+                                     _ptr(margin_out), _stream())
+    _lib.check(rc, "ppo_rollout_pack_params")
+    return out
 
 
-NET_F32, NET_F16_SPLIT = 0, 1      # include/ppo_amd.h: PPO_NET_F32, PPO_NET_F16_SPLIT
-_TANH_SCALE = 2.0 * 1.4426950408889634   # 2 log2(e): tanh(x) = 1 - 2 / (exp2(_TANH_SCALE x) + 1)
-
-
-def _split_f16(x64: torch.Tensor):
-    """x (float64) -> (hi, lo) float16 with x ~= hi + lo (rollout.hip, mode 1); lo may be an f16
-    subnormal, which bounds its error by 2^-25 absolute."""
-    hi = x64.to(torch.float16)
-    lo = (x64 - hi.to(torch.float64)).to(torch.float16)
-    return hi, lo
-
-
-def _f16_words(t16: torch.Tensor) -> torch.Tensor:
-    """[..., 8] float16 -> [..., 4] float32 holding the same bits (two f16 per 32-bit word)."""
-    return t16.contiguous().view(torch.float32)
-
-
-def _backbone_f16_split(seq) -> list:
-    """One backbone in the mode-1 layout: W1[op][piece][lane][4], W2[j][op][piece][lane][4],
-    B2[op][r][lane]; weights and biases pre-multiplied by 2 log2(e) in float64 before the split."""
-    W1 = seq[0].weight.detach().to(torch.float64) * _TANH_SCALE      # [64, OBS]
-    b1 = seq[0].bias.detach().to(torch.float64) * _TANH_SCALE
-    W2 = seq[2].weight.detach().to(torch.float64) * _TANH_SCALE      # [64, 64]
-    b2 = seq[2].bias.detach().to(torch.float64) * _TANH_SCALE
-    dev = W1.device
-    obs = W1.shape[1]
-    assert obs < 8
-    lane = torch.arange(64, device=dev)
-    half, l31 = lane >> 5, lane & 31
-    # layer 1: k = i for both lane halves; the bias rides on input slot i = obs (the kernel feeds 1.0 there)
-    a1 = W1.new_zeros(2, 64, 8)
-    for op in range(2):
-        a1[op, :, :obs] = W1[32 * op + l31]
-        a1[op, :, obs] = b1[32 * op + l31]
-    h1, l1 = _split_f16(a1)
-    w1 = torch.stack([_f16_words(h1), _f16_words(l1)], dim=1)        # [op, piece, lane, 4]
-    # layer 2: k-step j = 2 o_in + (r_in >> 3), element i = r_in & 7 -> unit(o_in, r_in, half)
-    j = torch.arange(4, device=dev)[:, None, None]
-    i = torch.arange(8, device=dev)[None, None, :]
-    unit = _d_layout_unit(j >> 1, 8 * (j & 1) + i, half[None, :, None])          # [4, 64, 8]
-    a2 = torch.stack([W2[(32 * op + l31)[None, :, None], unit] for op in range(2)], dim=1)   # [j, op, lane, 8]
-    h2, l2 = _split_f16(a2)
-    w2 = torch.stack([_f16_words(h2), _f16_words(l2)], dim=2)        # [j, op, piece, lane, 4]
-    o = torch.arange(2, device=dev)[:, None, None]
-    r = torch.arange(16, device=dev)[None, :, None]
-    bb = b2[_d_layout_unit(o, r, half[None, None, :])].to(torch.float32)         # [op, r, lane]
-    return [w1.reshape(-1), w2.reshape(-1), bb.reshape(-1)]
-
-
-def pack_dense_agent_reference(agent, net_mode: int = NET_F32) -> torch.Tensor:
-    """Straightforward form of pack_dense_agent (dozens of small tensor ops; the definition the
-    planned form below is tested against).  Flatten a dense Agent's parameters into the layout k_rollout reads (rollout.hip): per
-    backbone the MFMA fragments of both tanh layers -- f32 fragments, the second layer in
-    register-chained k order (NET_F32), or two-piece f16 splits of the 2 log2(e)-scaled weights
-    (NET_F16_SPLIT) -- then the per-lane head weights HL[4][2][16][64] (j = 0..2 logits zero padded,
-    j = 3 critic) and bias4 = (policy bias zero padded to 3, critic bias)."""
-    def backbone(seq):
-        if net_mode == NET_F16_SPLIT:
-            return _backbone_f16_split(seq)
-        return [_mfma_frags(seq[0].weight, seq[0].bias), _mfma_frags(seq[2].weight, seq[2].bias, chained=True)]
-    with torch.no_grad():
-        parts = backbone(agent.pi_backbone)
-        if not agent.joint_net:
-            parts += backbone(agent.va_backbone)
-        A = agent.policy.weight.shape[0]
-        assert A <= 3
-        dev = agent.policy.weight.device
-        wh = agent.policy.weight.new_zeros(4, 64)
-        wh[:A] = agent.policy.weight
-        wh[3] = agent.critic.weight.reshape(-1)
-        lane = torch.arange(64, device=dev)
-        o = torch.arange(2, device=dev)[:, None, None]
-        r = torch.arange(16, device=dev)[None, :, None]
-        unit = _d_layout_unit(o, r, (lane >> 5)[None, None, :])              # [2, 16, 64]
-        hl = wh[:, unit]                                                     # [4, 2, 16, 64]
-        bias4 = agent.policy.bias.new_zeros(4)
-        bias4[:A] = agent.policy.bias
-        bias4[3] = agent.critic.bias[0]
-        parts += [hl.reshape(-1), bias4]
-        return torch.cat([p.detach().to(torch.float32).reshape(-1) for p in parts]).contiguous()
-
-
-class _PackPlan:
-    """pack_dense_agent as a handful of gathers.  The layout never changes for a given network shape,
-    so it is worked out once -- by running the reference packing code on tensors of INDICES into the
-    flattened parameter vector instead of on values -- and a pack is then: concatenate the
-    parameters, gather, scale, split into f16 pieces, gather into place.  (The step-by-step form
-    costs 0.6-1.0 ms of small launches per rollout in training, as much as the rollout kernel.)"""
-
-    def __init__(self, agent, net_mode):
-        dev = agent.policy.weight.device
-        self.names = [n for n, _ in agent.named_parameters()]
-        shapes = {n: p.shape for n, p in agent.named_parameters()}
-        offs, total = {}, 0
-        for n in self.names:
-            offs[n] = total
-            total += int(np.prod(shapes[n]))
-        self.pad = total                                   # index of the appended 0.0
-
-        def idx(name):
-            return (offs[name] + torch.arange(int(np.prod(shapes[name])), device=dev)).reshape(shapes[name])
-
-        def seq_idx(prefix):                               # Sequential(Linear, Tanh, Linear, Tanh)
-            return idx(prefix + ".0.weight"), idx(prefix + ".0.bias"), idx(prefix + ".2.weight"), idx(prefix + ".2.bias")
-
-        lane = torch.arange(64, device=dev)
-        half, l31 = lane >> 5, lane & 31
-        pad = self.pad
-        seg16, seg32 = [], []                              # (src, is_lo) element lists; (src, scale) lists
-        order = []                                         # final layout: ("h", n_words) / ("f", n_floats) in sequence
-        backbones = ["pi_backbone"] + ([] if agent.joint_net else ["va_backbone"])
-        for bbn in backbones:
-            W1, b1, W2, b2 = seq_idx(bbn)
-            obs = W1.shape[1]
-            if net_mode == NET_F16_SPLIT:
-                assert obs < 8
-                a1 = torch.full((2, 64, 8), pad, dtype=torch.long, device=dev)
-                for op in range(2):
-                    a1[op, :, :obs] = W1[32 * op + l31]
-                    a1[op, :, obs] = b1[32 * op + l31]
-                j = torch.arange(4, device=dev)[:, None, None]
-                i = torch.arange(8, device=dev)[None, None, :]
-                unit = _d_layout_unit(j >> 1, 8 * (j & 1) + i, half[None, :, None])
-                a2 = torch.stack([W2[(32 * op + l31)[None, :, None], unit] for op in range(2)], dim=1)   # [j, op, lane, 8]
-                for src, piece_dim in ((a1, 1), (a2, 2)):
-                    e = torch.stack([src, src], dim=piece_dim)                  # hi block, lo block
-                    lo = torch.zeros_like(e, dtype=torch.bool)
-                    lo.select(piece_dim, 1).fill_(True)
-                    seg16.append((e.reshape(-1), lo.reshape(-1)))
-                    order.append(("h", e.numel() // 2))
-                o = torch.arange(2, device=dev)[:, None, None]
-                r = torch.arange(16, device=dev)[None, :, None]
-                bsrc = b2[_d_layout_unit(o, r, half[None, None, :])].reshape(-1)
-                seg32.append((bsrc, torch.full_like(bsrc, 0, dtype=torch.float64) + _TANH_SCALE))
-                order.append(("f", bsrc.numel()))
-            else:
-                for W, b, chained in ((W1, b1, False), (W2, b2, True)):
-                    K = W.shape[1]
-                    if K % 2:
-                        W = torch.cat([W, torch.full((64, 1), pad, dtype=torch.long, device=dev)], dim=1)
-                        K += 1
-                    sidx = torch.arange(K // 2, device=dev)
-                    if chained:
-                        col = _d_layout_unit((sidx // 16)[:, None], (sidx % 16)[:, None], half[None, :])
-                    else:
-                        col = 2 * sidx[:, None] + half[None, :]
-                    frag = torch.full((1 + K // 2, 2, 64), pad, dtype=torch.long, device=dev)
-                    for o in range(2):
-                        frag[0, o] = torch.where(half == 0, b[32 * o + l31], torch.full_like(l31, pad))
-                        frag[1:, o] = W[(32 * o + l31)[None, :], col]
-                    seg32.append((frag.reshape(-1), torch.ones(frag.numel(), dtype=torch.float64, device=dev)))
-                    order.append(("f", frag.numel()))
-        A = shapes["policy.weight"][0]
-        assert A <= 3
-        wh = torch.full((4, 64), pad, dtype=torch.long, device=dev)
-        wh[:A] = idx("policy.weight")
-        wh[3] = idx("critic.weight").reshape(-1)
-        o = torch.arange(2, device=dev)[:, None, None]
-        r = torch.arange(16, device=dev)[None, :, None]
-        hl = wh[:, _d_layout_unit(o, r, (lane >> 5)[None, None, :])].reshape(-1)
-        bias4 = torch.full((4,), pad, dtype=torch.long, device=dev)
-        bias4[:A] = idx("policy.bias")
-        bias4[3] = idx("critic.bias")[0]
-        tail = torch.cat([hl, bias4])
-        seg32.append((tail, torch.ones(tail.numel(), dtype=torch.float64, device=dev)))
-        order.append(("f", tail.numel()))
-        # element lists, and where each output word comes from in cat([f16 words, f32 values])
-        self.src16 = torch.cat([e for e, _ in seg16]) if seg16 else None
-        self.lo16 = torch.cat([m for _, m in seg16]) if seg16 else None
-        self.src32 = torch.cat([e for e, _ in seg32])
-        self.scale32 = torch.cat([c for _, c in seg32])
-        n_words = 0 if self.src16 is None else self.src16.numel() // 2
-        perm, at_h, at_f = [], 0, n_words
-        for kind, n in order:
-            if kind == "h":
-                perm.append(torch.arange(at_h, at_h + n, device=dev)); at_h += n
-            else:
-                perm.append(torch.arange(at_f, at_f + n, device=dev)); at_f += n
-        self.perm = torch.cat(perm)
-
-    def pack(self, agent) -> torch.Tensor:
-        params = dict(agent.named_parameters())
-        flat = [params[n].detach().reshape(-1) for n in self.names]
-        theta = torch.cat(flat + [flat[0].new_zeros(1)]).to(torch.float64)
-        parts = []
-        if self.src16 is not None:
-            v = theta[self.src16] * _TANH_SCALE
-            hi = v.to(torch.float16)
-            lo = (v - hi.to(torch.float64)).to(torch.float16)
-            parts.append(torch.where(self.lo16, lo, hi).view(torch.float32))
-        parts.append((theta[self.src32] * self.scale32).to(torch.float32))
-        return torch.cat(parts)[self.perm].contiguous()
-
-
-_PACK_PLANS: dict = {}
-
-
-def pack_dense_agent(agent, net_mode: int = NET_F32) -> torch.Tensor:
-    """Flatten a dense Agent's parameters into the layout k_rollout reads (rollout.hip; element by
-    element the same as pack_dense_agent_reference).  The gather plan is cached per network shape,
-    mode and device."""
-    key = (int(net_mode), bool(agent.joint_net), str(agent.policy.weight.device),
-           tuple((n, tuple(p.shape)) for n, p in agent.named_parameters()))
-    plan = _PACK_PLANS.get(key)
-    if plan is None:
-        plan = _PACK_PLANS[key] = _PackPlan(agent, net_mode)
-    with torch.no_grad():
-        return plan.pack(agent)
+def resolve_net_mode(agent, net_mode: int):
+    """(params, mode actually used, split_ok or None) for a requested mode.  NET_AUTO packs for the
+    split kernels, reads the margin back (one small device->host copy) and falls back to the exact-f32
+    layout when the parameter set fails it."""
+    if net_mode != NET_AUTO:
+        return pack_dense_agent(agent, net_mode), net_mode, None
+    margin = torch.empty(1, dtype=torch.float32, device=agent.policy.weight.device)
+    params = pack_dense_agent(agent, NET_F16_SPLIT, margin_out=margin)
+    ok = float(margin.item()) >= SPLIT_MARGIN_MIN
+    if ok:
+        return params, NET_F16_SPLIT, True
+    return pack_dense_agent(agent, NET_F32), NET_F32, False
 
 
 def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, log_probs, values, rewards, done,

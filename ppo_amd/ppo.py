@@ -192,7 +192,6 @@ class SyncVecEnv:
         self._stats_pending = False
         self._stats5 = None
         self._rsum_pool, self._rsum_next = torch.empty(0), 0
-        self._packed = (None, None)
         self._total_return = np.float32(0.0)
         self._end_states = None
         self.state_space, self.action_space = agent.state_space, agent.action_space
@@ -203,9 +202,14 @@ class SyncVecEnv:
         # env transition) in ONE kernel launch.  False = PyTorch MLP + one env kernel per time step.
         self.fused_rollout = True
         # how the whole-rollout kernel multiplies inside the network (include/ppo_amd.h): exact f32
-        # MFMA products (ops.NET_F32), or f16 MFMAs on two-piece splits (ops.NET_F16_SPLIT, ~1.5x faster,
-        # 22 bits per operand); PPO_AMD_NET=f32 selects the former
-        self.net_mode = ops.NET_F32 if os.environ.get("PPO_AMD_NET", "f16_split") == "f32" else ops.NET_F16_SPLIT
+        # MFMA products (ops.NET_F32), f16 MFMAs on two-piece splits (ops.NET_F16_SPLIT, ~1.9x faster,
+        # 22 bits per operand), or -- the default -- the split kernels whenever the pack kernel's
+        # split_margin says they are as accurate as f32 for the current parameters, f32 otherwise
+        # (ops.NET_AUTO).  PPO_AMD_NET = auto | f32 | f16_split.
+        self.net_mode = {"auto": ops.NET_AUTO, "f32": ops.NET_F32, "f16_split": ops.NET_F16_SPLIT}[
+            os.environ.get("PPO_AMD_NET", "auto")]
+        self.net_mode_used = None    # what the last whole-rollout launch ran (NET_F32 / NET_F16_SPLIT)
+        self._pack = None            # parameters packed for the rollout kernel, see _net()
         self.wave_envs = 0           # tests / tuning: force 32 or 64 envs per wave (0 = the library chooses by N)
         self._rollouts = 0
 
@@ -312,10 +316,12 @@ class SyncVecEnv:
                 self._rsum_pool, self._rsum_next = torch.zeros(64, dtype=torch.float64, device=kdev), 0
             rsum = self._rsum_pool[self._rsum_next:self._rsum_next + 1]
             self._rsum_next += 1
-            ops.rollout_fused(b, self._packed_params(), self.agent.joint_net, self._rollouts * T, carry,
+            params, mode = self._net()
+            ops.rollout_fused(b, params, self.agent.joint_net, self._rollouts * T, carry,
                               self.states, self.actions, self.log_probs, self.values, self.rewards,
                               self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T,
-                              net_mode=self.net_mode, reward_sum=rsum, wave_envs=self.wave_envs)
+                              net_mode=mode, reward_sum=rsum, wave_envs=self.wave_envs)
+            self.net_mode_used = mode
             self._ev_ready = True                      # bootstrap values already written by the kernel
         else:
             carry = torch.empty((N, b.obs_dim), dtype=torch.float32, device=kdev)
@@ -351,13 +357,42 @@ class SyncVecEnv:
         # of behind 150 MB of ring reads.  Same values: only rollout / step kernels change the rings.
         self._stats_pending = True
 
-    def _packed_params(self) -> torch.Tensor:
-        """Network in the whole-rollout kernel's layout; repacked only when a parameter changed
-        (torch bumps a tensor's _version on every in-place update, i.e. on every optimiser step)."""
+    def prepack(self):
+        """Queue the pack kernel(s) for the current parameters if they changed since the last pack
+        (torch bumps a tensor's _version on every in-place update, i.e. on every optimiser step); no
+        host synchronisation.  PPO.train_step calls this right behind the last optimizer.step() of an
+        update, so that the next rollout starts with its parameters packed.  Returns the device f32[1]
+        split margin still to be read (ops.NET_AUTO), else None."""
         key = (self.net_mode,) + tuple((id(p), p._version) for p in self.agent.parameters())
-        if self._packed[0] != key:
-            self._packed = (key, ops.pack_dense_agent(self.agent, self.net_mode))
-        return self._packed[1]
+        pk = self._pack
+        if pk is not None and pk["key"] == key:
+            return pk["margin"] if pk["ok"] is None else None
+        if pk is None or pk["mode"] != self.net_mode:
+            pk = self._pack = {"mode": self.net_mode, "bufs": {}, "margin": None}
+            if self.net_mode == ops.NET_AUTO:
+                pk["margin"] = torch.empty(1, dtype=torch.float32, device=self.kdev)
+        pk["key"] = key
+        modes = (ops.NET_F16_SPLIT, ops.NET_F32) if self.net_mode == ops.NET_AUTO else (self.net_mode,)
+        for m in modes:                                    # AUTO: both layouts (two 5 us launches), decided below
+            pk["bufs"][m] = ops.pack_dense_agent(self.agent, m, out=pk["bufs"].get(m),
+                                                 margin_out=pk["margin"] if m == ops.NET_F16_SPLIT else None)
+        pk["ok"] = None if self.net_mode == ops.NET_AUTO else True
+        return pk["margin"]
+
+    def note_split_margin(self, margin: float):
+        """The host value of prepack()'s margin (read by the caller together with its other scalars)."""
+        self._pack["ok"] = bool(margin >= ops.SPLIT_MARGIN_MIN)
+
+    def _net(self):
+        """(packed parameters, network mode) for the next whole-rollout launch."""
+        pending = self.prepack()
+        if pending is not None:                            # not read by the caller: one small device->host copy
+            self.note_split_margin(float(pending.item()))
+        pk = self._pack
+        if self.net_mode != ops.NET_AUTO:
+            return pk["bufs"][self.net_mode], self.net_mode
+        mode = ops.NET_F16_SPLIT if pk["ok"] else ops.NET_F32
+        return pk["bufs"][mode], mode
 
     def _locate_end_states(self):
         """end_states: terminal observations, actor-major / time-ascending (reference :401-402).
@@ -554,6 +589,8 @@ class PPO:
         # Discrete heads: log-prob, entropy, ratio and losses in one kernel (ppo_loss_logits_fwd_bwd);
         # False keeps torch.distributions.Categorical in front of ppo_loss_fwd_bwd.
         self.fused_discrete_loss = True
+        self.minibatch_hook = None   # tests: called with a dict per minibatch (indices, losses) when set
+        self._idle = False           # True while nothing of ours is queued on the device (set by a host read-back)
 
     # -- hot path: GAE --------------------------------------------------------------------
     def compute_advantages(self, rewards, values, end_values, done_flags, trunc_flags):
@@ -576,14 +613,22 @@ class PPO:
         ve = self.vec_env
         num_envs, steps_per_env = ve.num_envs, ve.steps_per_env
         world = ppo_dist.world_size()
+        # Data parallel: batch_size is the GLOBAL minibatch, every rank contributes batch_size / world
+        # samples of its own env shard, so the number of optimiser steps and the samples behind each
+        # gradient are those of the single-process run (reference src/ppo.py:578-588).
+        if batch_size % world != 0 or batch_size < world:
+            raise ValueError(f"batch_size={batch_size} must be a positive multiple of world_size={world}")
+        local_batch = batch_size // world
 
-        _sync()                                    # the previous update's kernels are not part of this bracket
+        if not self._idle:                         # the previous update's kernels are not part of this bracket
+            _sync()                                # (skipped when that update ended in a host read-back: nothing is queued)
+        self._idle = False
         rollout_start = time.time()
         ve.rollout()
         with torch.no_grad():
             advantages = self._rollout_advantages(ve)
         _sync()
-        rollout_time = time.time() - rollout_start
+        rollout_time = ppo_dist.max_scalar(time.time() - rollout_start)   # the job waits for its slowest rank
         env_steps_per_sec = steps_per_env * num_envs * world / rollout_time
 
         states = ve.states.detach().flatten(0, 1)  # no gradient wrt observations is ever used
@@ -605,8 +650,8 @@ class PPO:
                         and states.dtype == torch.float32)
         for _epoch in range(num_epochs):
             perm = torch.randperm(data_size, device=dev)       # reference :575-576 (np.random.shuffle)
-            for start in range(0, data_size, batch_size):
-                idx = perm[start:start + batch_size]           # last minibatch may be short (:581)
+            for start in range(0, data_size, local_batch):
+                idx = perm[start:start + local_batch]          # last minibatch may be short (:581)
                 if fused_gather:                               # one launch for the five gathers (:582-588)
                     mb_states, mb_actions, mb_log_probs, mb_values, mb_adv = ops.minibatch_gather(
                         idx, states, actions, log_probs, values, advantages)
@@ -651,16 +696,30 @@ class PPO:
                     early = early | (kl_all > target_div).to(dev)
                 clip_sum += clip_frac.detach().to(dev)
                 grad_steps_done += 1
+                if self.minibatch_hook is not None:
+                    self.minibatch_hook(dict(update=self.updates, epoch=_epoch, start=start, idx=idx,
+                                             policy_loss=policy_loss.detach(), critic_loss=critic_loss.detach(),
+                                             entropy=entropy.detach(), kl_div=kl_div.detach()))
             if target_div is not None and bool(early.item()):  # checked at the end of an epoch (:634)
                 break
-        _sync()
-        updates_time = time.time() - updates_start
+        # the next rollout's parameters are packed here, right behind the last optimizer.step(): the
+        # rollout bracket of the next update starts with a kernel launch, not with host-side packing
+        margin = ve.prepack() if (ve.native and ve.fused_rollout and dev.type == "cuda") else None
+        # one device->host copy for every scalar of this update (it is also the update's final sync)
+        scalars = [policy_loss.detach().to(dev), critic_loss.detach().to(dev), entropy.detach().to(dev),
+                   kl_div.detach().to(dev), clip_sum]
+        if margin is not None:
+            scalars.append(margin[0].to(dev))
+        host = torch.stack([s.to(torch.float32).reshape(()) for s in scalars]).cpu().tolist()
+        if margin is not None:
+            ve.note_split_margin(host[5])
+        updates_time = ppo_dist.max_scalar(time.time() - updates_start)
+        self._idle = dev.type == "cuda" and world == 1
         grad_steps_per_sec = grad_steps_done / updates_time
         global_steps_per_sec = steps_per_env * num_envs * world / (rollout_time + updates_time)
 
-        policy_loss, critic_loss = policy_loss.item(), critic_loss.item()
-        entropy, kl_div = entropy.item(), kl_div.item()
-        clip_frac = float(clip_sum.item() / max(grad_steps_done, 1))
+        policy_loss, critic_loss, entropy, kl_div = host[0], host[1], host[2], host[3]
+        clip_frac = float(host[4] / max(grad_steps_done, 1))
         rollout_return = float(ve.total_return) / num_envs
         ep_return_max = float(ve.max_ep_return)
         self.last_metrics = {  # reference :656-670, same names

@@ -1,0 +1,158 @@
+"""GPU: the whole-rollout kernel at the shapes bench.py and BASELINE.json time -- CartPole
+N = 65536 x T = 128 (configs[1]; 1024 full 64-env waves, both network modes), Acrobot N = 32768
+(configs[2]'s per-GPU shard on 8 GPUs; 32-env waves) and Acrobot N = 262144 (configs[2] whole) --
+through the default wave choice of ppo_rollout_fused.  Replaces the loop of reference
+src/ppo.py:320-398 inside the bracket of :544-560.
+
+Per config, two consecutive rollouts; for each:
+ (i)   the recorded actions of column slices that straddle wave and workgroup boundaries (and the
+       tail of the batch) are replayed through the oracle's env batch started from the device's own
+       fp64 state: flags, rewards, TimeLimit / episode counters and statistics rings bit-exact,
+       observations to 1e-5;
+ (ii)  values / log-probs of ALL T*N samples against the PyTorch f32 forward (1e-5 relative + 2e-6);
+       the sampled actions against the Philox draw applied to the PyTorch logits, exact outside a
+       1e-5 band around the CDF boundaries;
+ (iii) ppo_gae_dense on the kernel's own buffers against the oracle on the slices, bit-exact;
+ (iv)  total_return == sum of the rewards.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+SNAP = ("state", "elapsed", "ep_ret", "ep_len", "episode", "ret_ring", "len_ring", "ring_cnt")
+
+
+def _slices(N):
+    mid = 48 * 256 + 37                      # not a multiple of 32 / 64 / 256: crosses 8+ workgroups
+    return [(mid, 2048), (N - 300, 300), (0, 70)]
+
+
+def _oracle_from_device(kind, batch, s0, n, seed):
+    ora = cref.BatchEnv(kind, n, seed=seed, env_base=batch.env_base + s0)
+    for name in SNAP:
+        src = getattr(batch, name)[s0:s0 + n].cpu().numpy()
+        dst = getattr(ora, name)
+        dst[...] = src.view(dst.dtype) if src.dtype != dst.dtype else src
+    return ora
+
+
+def _forward_chunked(agent, states_flat, actions_flat, chunk=1 << 22):
+    lps, vals, lgs = [], [], []
+    with torch.no_grad():
+        for i in range(0, states_flat.shape[0], chunk):
+            logits, v = agent.policy_and_values(states_flat[i:i + chunk])
+            lp = torch.log_softmax(logits, 1).gather(1, actions_flat[i:i + chunk].long()[:, None])[:, 0]
+            lps.append(lp); vals.append(v); lgs.append(logits)
+    return torch.cat(lps), torch.cat(vals), torch.cat(lgs)
+
+
+CONFIGS = [
+    pytest.param("cartpole", 65536, "f16_split", id="C2_cartpole_65536_f16_split_wave64"),
+    pytest.param("cartpole", 65536, "f32", id="C2_cartpole_65536_f32"),
+    pytest.param("acrobot", 32768, "f16_split", id="C3_shard_acrobot_32768_wave32"),
+    pytest.param("acrobot", 262144, "f16_split", id="C3_acrobot_262144_wave64"),
+]
+
+
+@pytest.mark.parametrize("kind,N,mode", CONFIGS)
+def test_fused_rollout_at_benchmarked_shape(kind, N, mode):
+    from ppo_amd import Agent, SyncVecEnv, ops
+    from ppo_amd.envs import DeviceEnv
+    T, seed = 128, 31
+    torch.manual_seed(1)
+    probe = DeviceEnv(kind)
+    agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
+    with torch.no_grad():                     # away from the near-uniform init: non-trivial log-probs
+        agent.policy.weight.mul_(50.0)
+        agent.policy.bias.uniform_(-0.3, 0.3)
+        agent.critic.bias.fill_(0.2)
+    ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=seed), N, T, 0, 0.0, agent, seed=seed)
+    assert ve.wave_envs == 0                  # the library's own choice, as in bench.py
+    ve.net_mode = ops.NET_F32 if mode == "f32" else ops.NET_F16_SPLIT
+    # some envs close to the 500-step limit, so that mid-rollout truncations (and their bootstrap
+    # values from the kernel's second network pass) occur at this scale too
+    g = torch.Generator(device="cuda").manual_seed(2)
+    near = torch.randint(0, N, (N // 16,), device="cuda", generator=g)
+    ve.batch.elapsed[near] = torch.randint(380, 499, (near.numel(),), device="cuda", generator=g, dtype=torch.int32)
+    od = ve.batch.obs_dim
+
+    for k in range(2):
+        oracles = [(s0, n, _oracle_from_device(kind, ve.batch, s0, n, seed)) for s0, n in _slices(N)]
+        obs0 = ve.t_states.clone()
+        ve.rollout()
+        assert ve._ev_ready
+        st = ve.states.detach()
+        assert torch.equal(st[0], obs0)       # row 0 holds the carried observations (src/ppo.py:390, :398)
+        done, trunc = ve.done_flags, ve.trunc_flags
+        assert bool(((done + trunc)[-1] > 0).all())          # forced truncation of the last row (:352-356)
+        # (iv) total_return (:318, :348): rewards are integer-valued for both envs, so the sum is exact
+        assert float(ve.total_return) == float(ve.rewards.sum(dtype=torch.float64))
+
+        # (ii) every sample against the PyTorch forward
+        lp_ref, v_ref, logits = _forward_chunked(agent, st.flatten(0, 1), ve.actions.flatten())
+        assert torch.allclose(ve.log_probs.flatten(), lp_ref, rtol=1e-5, atol=2e-6)
+        assert torch.allclose(ve.values.flatten(), v_ref, rtol=1e-5, atol=2e-6)
+        # bootstrap values of every truncated cell == critic(terminal observation) (:555, :478)
+        trm = trunc > 0
+        with torch.no_grad():
+            want_ev = agent.get_values(ve._term_obs[trm])
+        assert torch.allclose(ve._ev_dense[trm], want_ev, rtol=1e-5, atol=2e-6)
+        assert int(trm[:-1].sum()) > 0 or k == 1             # mid-rollout TimeLimit hits did occur
+
+        # sampled actions: the Philox draw of (seed; env, step) applied to the PyTorch logits
+        lg_np = logits.view(T, N, -1)
+        for t in (0, 1, T // 2, T - 1):
+            u = cref.sample_uniform(seed, 0, k * T + t, N)
+            bad, amb = cref.categorical_check(lg_np[t].cpu().numpy(), u, ve.actions[t].cpu().numpy())
+            assert bad == 0 and amb < N // 200, (t, bad, amb)
+
+        # (iii) GAE on the kernel's own buffers
+        adv = ops.gae_dense(ve.rewards, ve.values, ve._ev_dense, done, trunc, 0.99, 0.95)
+        evz = torch.where(trm, ve._ev_dense, torch.zeros_like(ve._ev_dense))   # defined only where trunc != 0
+
+        for s0, n, ora in oracles:
+            sl = slice(s0, s0 + n)
+            acts = ve.actions[:, sl].cpu().numpy()
+            d_np, tr_np, r_np = done[:, sl].cpu().numpy(), trunc[:, sl].cpu().numpy(), ve.rewards[:, sl].cpu().numpy()
+            st_np = st[:, sl].cpu().numpy()
+            carry = ve.t_states[sl].cpu().numpy()
+            term_np = ve._term_obs[:, sl].cpu().numpy()
+            for t in range(T):
+                o, term, r, d, tr = ora.step(acts[t], is_last=(t == T - 1))
+                assert np.array_equal(d, d_np[t]) and np.array_equal(tr, tr_np[t]), (k, s0, t)
+                assert np.array_equal(r, r_np[t])
+                nxt = st_np[t + 1] if t + 1 < T else carry
+                assert np.allclose(nxt, o, rtol=1e-5, atol=1e-5), (k, s0, t, float(np.abs(nxt - o).max()))
+                ended = (d + tr) > 0
+                assert np.allclose(term_np[t][ended], term[ended], rtol=1e-5, atol=1e-5)
+            for name in ("elapsed", "ep_len", "episode", "ring_cnt", "len_ring"):   # integer bookkeeping: exact
+                dev = getattr(ve.batch, name)[sl].cpu().numpy()
+                want = getattr(ora, name)
+                assert np.array_equal(dev.view(want.dtype), want), (k, s0, name)
+            assert np.array_equal(ve.batch.ep_ret[sl].cpu().numpy(), ora.ep_ret)     # integer-valued returns
+            assert np.array_equal(ve.batch.ret_ring[sl].cpu().numpy(), ora.ret_ring)
+            want_adv = cref.gae_dense(r_np, ve.values[:, sl].cpu().numpy(), evz[:, sl].cpu().numpy(), d_np, tr_np,
+                                      0.99, 0.95)
+            assert np.array_equal(adv[:, sl].cpu().numpy(), want_adv), (k, s0)
+
+
+def test_train_step_bracket_at_c2_shape():
+    """PPO.train_step at BASELINE configs[1] (reference bracket src/ppo.py:544-560 + one epoch of four
+    minibatches of T*N/4): runs, takes the fused paths, and its advantages equal ppo_gae_dense on the
+    rollout buffers."""
+    from ppo_amd import PPO, ops
+    from ppo_amd.env_cartpole import train_fn
+    torch.manual_seed(0)
+    ppo = PPO(0.99, 0.95, 1, 1, 0, 1, True, seed=5)
+    N, T = 65536, 128
+    ppo.train(train_fn, num_updates=2, num_envs=N, steps_per_env=T, num_epochs=1, batch_size=T * N // 4,
+              critic_coef=0.5, entropy_coef=0.01, clip_ratio=0.2, max_grad_norm=0.5, learning_rate=3e-4)
+    m = ppo.last_metrics
+    assert m["utils/env_steps_per_sec"] > 1e8 and np.isfinite(m["losses/policy_loss"])
+    assert m["utils/grad_steps_per_sec"] > 0 and m["utils/global_steps_per_sec"] > 0
+    ve = ppo.vec_env
+    assert ve._ev_ready and ve.states.shape == (T, N, 4)

@@ -1,0 +1,135 @@
+"""GPU: accuracy of the whole-rollout kernel's network forward over adversarial parameter scales
+and observations at their bounds -- PPO_NET_F16_SPLIT, PPO_NET_F32 and PyTorch's own f32 forward
+(hipBLASLt), each against a float64 forward of the same parameters on 2^18 states.
+
+What it replaces: Agent.get_actions_and_values under no_grad inside the rollout (reference
+src/ppo.py:337, network :124-145, :166-216), which the reference computes in f32.
+
+The f16-split mode keeps 22 significant bits per operand but the low piece of a value below 2^-3
+is an f16 subnormal (absolute error 2^-25), so SMALL weights lose relative precision.  The default
+network mode is therefore "auto": ppo_rollout_pack_params measures, per weight tensor, whether that
+floor stays below the mode's inherent 2^-22 relative error (split_ok) and the split kernels are used
+only then; otherwise the exact-f32 MFMA kernels run.  Asserted here, at every scale:
+  * auto-mode max error <= 1.5 x PyTorch-f32's max error (+ 4 ulp of the output scale), and
+  * <= 1e-5 relative (+ 2e-6) per sample,
+and that auto picks the split kernels for the init-scale / trained-scale networks the benchmark uses.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NSTATES = 1 << 18
+
+
+def _states(kind, n, gen):
+    if kind == "cartpole":   # observation_space bounds: x 4.8, theta 0.42; velocities are unbounded, 10 is far outside
+        bound = torch.tensor([4.8, 10.0, 0.42, 10.0], device="cuda")
+        u = torch.rand(n, 4, device="cuda", generator=gen) * 2 - 1
+        s = u * bound
+        corner = torch.where(torch.rand(n // 4, 4, device="cuda", generator=gen) < 0.5, -bound, bound)
+        s[: n // 4] = corner                                   # exactly at the bounds, all sign combinations
+        s[n // 4: n // 2] = u[n // 4: n // 2] * 0.05           # reset-like states: every input tiny
+        return s.contiguous()
+    th = (torch.rand(n, 2, device="cuda", generator=gen) * 2 - 1) * np.pi
+    vmax = torch.tensor([4 * np.pi, 9 * np.pi], device="cuda")
+    vel = (torch.rand(n, 2, device="cuda", generator=gen) * 2 - 1) * vmax
+    vel[: n // 4] = torch.where(torch.rand(n // 4, 2, device="cuda", generator=gen) < 0.5, -vmax, vmax)
+    s = torch.stack([th[:, 0].cos(), th[:, 0].sin(), th[:, 1].cos(), th[:, 1].sin(), vel[:, 0], vel[:, 1]], 1)
+    return s.float().contiguous()
+
+
+def _kernel_forward(kind, agent, states, mode):
+    """values, actions, log-probs of step 0 of a T = 1 rollout started from the given observations."""
+    from ppo_amd import ops
+    from ppo_amd.envs import DeviceEnvBatch
+    n, od = states.shape
+    b = DeviceEnvBatch(kind, n, seed=3)
+    b.reset()
+    params, used, split_ok = ops.resolve_net_mode(agent, mode)
+    obs_io = states.clone()
+    bufs = dict(states=torch.empty(1, n, od, device="cuda"), actions=torch.empty(1, n, dtype=torch.int32, device="cuda"),
+                log_probs=torch.empty(1, n, device="cuda"), values=torch.empty(1, n, device="cuda"),
+                rewards=torch.empty(1, n, device="cuda"), done=torch.empty(1, n, dtype=torch.int32, device="cuda"),
+                trunc=torch.empty(1, n, dtype=torch.int32, device="cuda"), term_obs=torch.empty(1, n, od, device="cuda"),
+                ev_dense=torch.empty(1, n, device="cuda"))
+    ops.rollout_fused(b, params, agent.joint_net, 0, obs_io, bufs["states"], bufs["actions"], bufs["log_probs"],
+                      bufs["values"], bufs["rewards"], bufs["done"], bufs["trunc"], bufs["term_obs"], bufs["ev_dense"],
+                      1, net_mode=used)
+    assert torch.equal(bufs["states"][0], states)
+    return bufs["values"][0], bufs["actions"][0], bufs["log_probs"][0], split_ok
+
+
+def _f64(agent, states, actions):
+    import copy
+    a64 = copy.deepcopy(agent).double()
+    with torch.no_grad():
+        logits, v = a64.policy_and_values(states.double())
+    lp = torch.log_softmax(logits, 1).gather(1, actions.long()[:, None])[:, 0]
+    return v, lp
+
+
+def _f32_torch(agent, states, actions):
+    with torch.no_grad():
+        logits, v = agent.policy_and_values(states)
+    lp = torch.log_softmax(logits, 1).gather(1, actions.long()[:, None])[:, 0]
+    return v, lp
+
+
+SCALES = [1e-4, 1e-2, 0.25, 1.0, 30.0]
+
+
+@pytest.mark.parametrize("joint", [1, 0], ids=["joint", "split"])
+@pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
+def test_network_error_vs_float64_over_scales(kind, joint):
+    from ppo_amd import Agent, ops
+    from ppo_amd.envs import DeviceEnv
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    states = _states(kind, NSTATES, gen)
+    probe = DeviceEnv(kind)
+    report = []
+    for scale in SCALES:
+        for head_gain, bias_amp in ((1.0, 0.0), (60.0, 5.0)):
+            torch.manual_seed(int(scale * 1e4) + int(head_gain))
+            agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=joint, device="cuda")
+            with torch.no_grad():
+                bbs = [agent.pi_backbone] + ([] if joint else [agent.va_backbone])
+                for bb in bbs:
+                    for lin in (bb[0], bb[2]):
+                        lin.weight.mul_(scale)
+                        if bias_amp:
+                            lin.bias.uniform_(-bias_amp, bias_amp)
+                agent.policy.weight.mul_(head_gain)
+                if bias_amp:
+                    agent.policy.bias.uniform_(-1.0, 1.0)
+                    agent.critic.bias.fill_(0.7)
+            res = {}
+            for name, mode in (("auto", ops.NET_AUTO), ("split", ops.NET_F16_SPLIT), ("f32", ops.NET_F32)):
+                v, act, lp, split_ok = _kernel_forward(kind, agent, states, mode)
+                v64, lp64 = _f64(agent, states, act)
+                res[name] = ((v.double() - v64).abs(), (lp.double() - lp64).abs(), v64, lp64, split_ok)
+            act = torch.zeros(NSTATES, dtype=torch.int32, device="cuda")
+            v64, lp64 = _f64(agent, states, act)
+            vt, lpt = _f32_torch(agent, states, act)
+            ev_t, el_t = float((vt.double() - v64).abs().max()), float((lpt.double() - lp64).abs().max())
+            row = dict(kind=kind, joint=joint, scale=scale, head=head_gain, split_ok=bool(res["auto"][4]),
+                       torch_v=ev_t, torch_lp=el_t)
+            for name in ("auto", "split", "f32"):
+                row[name + "_v"], row[name + "_lp"] = float(res[name][0].max()), float(res[name][1].max())
+            report.append(row)
+            print(row)
+            ev, el, v64a, lp64a, split_ok = res["auto"]
+            # per sample: 1e-5 relative (+ 2e-6, the f32 summation-order floor the other tests use)
+            assert bool((ev <= 1e-5 * v64a.abs() + 2e-6).all()), row
+            assert bool((el <= 1e-5 * lp64a.abs() + 2e-6).all()), row
+            # against PyTorch's own f32 forward: at most 1.5 x its max error, + 4 ulp of the output scale
+            ulp4_v = 2.0 ** -22 * max(float(v64a.abs().max()), 1e-3)
+            ulp4_l = 2.0 ** -22 * max(float(lp64a.abs().max()), 1e-3)
+            assert row["auto_v"] <= 1.5 * ev_t + ulp4_v, row
+            assert row["auto_lp"] <= 1.5 * el_t + ulp4_l, row
+            if scale >= 0.25:         # the networks the benchmark and training actually run: split kernels
+                assert split_ok, row
+            if split_ok:              # wherever auto chose the split kernels, the forced-split figures are the same run
+                assert row["split_v"] == row["auto_v"] and row["split_lp"] == row["auto_lp"]
+    assert any(not r["split_ok"] for r in report)      # and the guard does trip for the tiny-weight networks

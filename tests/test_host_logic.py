@@ -157,25 +157,3 @@ def test_cli_positional_order_matches_reference():
     assert (a.norm_adv, a.clip_va_loss, a.conv_net, a.joint_network, a.use_gpu, a.target_div) == (1, 1, 0, 0, 1, 0.01)
     assert a.render_every == 0 and a.render_fps == 0.0 and a.early_stop_reward is None
     assert callable(ppo_cli.resolve_env_fn("env_acrobot"))
-
-
-@pytest.mark.parametrize("obs,actions,joint", [(4, 2, 1), (4, 2, 0), (6, 3, 1), (6, 3, 0)])
-@pytest.mark.parametrize("net_mode", [0, 1])
-def test_planned_parameter_packing_equals_the_reference_form(obs, actions, joint, net_mode):
-    """ops.pack_dense_agent (cached gather plan, a dozen tensor ops) produces, bit for bit, what the
-    step-by-step pack_dense_agent_reference produces, for both network modes of the rollout kernel;
-    a second pack after a parameter update reuses the plan."""
-    import numpy as np
-    import torch
-    from ppo_amd import ops, spaces
-    from ppo_amd.ppo import Agent
-    torch.manual_seed(obs * 10 + joint)
-    agent = Agent(spaces.Box(-np.inf, np.inf, (obs,)), spaces.Discrete(actions), 0, joint, "cpu")
-    for _ in range(2):
-        with torch.no_grad():
-            for p in agent.parameters():
-                p.add_(0.3 * torch.randn_like(p))
-        want = ops.pack_dense_agent_reference(agent, net_mode)
-        got = ops.pack_dense_agent(agent, net_mode)
-        assert got.dtype == torch.float32 and got.shape == want.shape
-        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
