@@ -56,6 +56,25 @@ __global__ void __launch_bounds__(MB_BLOCK) k_minibatch_gather(GatherArgs a)
     }
 }
 
+// Wide rows (image observations: 84 x 84 x 4 f32 = 113 KB per sample, BASELINE configs[3]): one lane
+// per 16-byte piece of a row instead of one lane per sample, so that a wave moves 1 KiB of one row
+// per access instead of 64 words of 64 different rows.
+__global__ void __launch_bounds__(MB_BLOCK) k_gather_wide_rows(const int64_t *idx, const uint4 *src, uint4 *dst, long B,
+                                                               long M, long vec_per_row, int *err_flag)
+{
+    const long total = B * vec_per_row;
+    for (long e = (long)blockIdx.x * MB_BLOCK + threadIdx.x; e < total; e += (long)gridDim.x * MB_BLOCK) {
+        const long i = e / vec_per_row, w = e - i * vec_per_row;
+        long j = idx[i];
+        if (j < 0) j += M;
+        const bool ok = j >= 0 && j < M;
+        if (!ok && err_flag && w == 0) *err_flag = 1;
+        dst[e] = ok ? src[j * vec_per_row + w] : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+constexpr int WIDE_ROW_WORDS = 32;   // rows at least this wide (and 16-byte granular) take the wide-row kernel
+
 }  // namespace
 
 extern "C" {
@@ -83,11 +102,23 @@ int ppo_minibatch_gather(const int64_t *idx, long B, long M, const void *states,
     a.mb_log_probs = mb_log_probs; a.mb_values = mb_values; a.mb_adv = mb_adv;
     a.err_flag = err_flag;
     a.B = B; a.M = M; a.state_words = state_words; a.action_words = action_words;
+    hipStream_t s = (hipStream_t)stream;
+    if (states && state_words >= WIDE_ROW_WORDS && state_words % 4 == 0 && ppo_aligned(states, 16) &&
+        ppo_aligned(mb_states, 16)) {
+        const long vpr = state_words / 4;
+        long wb = (B * vpr + MB_BLOCK - 1) / MB_BLOCK;
+        if (wb > 16384) wb = 16384;
+        hipLaunchKernelGGL(k_gather_wide_rows, dim3((unsigned)wb), dim3(MB_BLOCK), 0, s, idx,
+                           static_cast<const uint4 *>(states), static_cast<uint4 *>(mb_states), B, M, vpr, err_flag);
+        const int rc = ppo_launch_status();
+        if (rc) return rc;
+        a.states = nullptr;                          // the per-sample kernel below moves the narrow arrays only
+    }
     a.state_vec4 = states && state_words == 4 && ppo_aligned(states, 16) && ppo_aligned(mb_states, 16);
     a.action_vec4 = actions && action_words == 4 && ppo_aligned(actions, 16) && ppo_aligned(mb_actions, 16);
     long blocks = (B + MB_BLOCK - 1) / MB_BLOCK;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_minibatch_gather, dim3((unsigned)blocks), dim3(MB_BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_minibatch_gather, dim3((unsigned)blocks), dim3(MB_BLOCK), 0, s, a);
     return ppo_launch_status();
 }
 

@@ -78,10 +78,13 @@ def merged_adv_stats(stats3: torch.Tensor) -> torch.Tensor:
     minibatch with the statistics of the GLOBAL minibatch."""
     if not is_dist():
         return stats3
-    gathered = [torch.empty_like(stats3) for _ in range(world_size())]
-    td.all_gather(gathered, stats3)
+    # every rank's triple in its own row of a zero matrix, summed: an all-gather made of the one
+    # collective that both RCCL and gloo run on device tensors
+    rows = stats3.new_zeros((world_size(), 3))
+    rows[rank()] = stats3
+    td.all_reduce(rows, op=td.ReduceOp.SUM)
     from .ops import merge_stats
-    return merge_stats([(g[0], g[1], g[2]) for g in gathered])
+    return merge_stats([(g[0], g[1], g[2]) for g in rows])
 
 
 def mean_scalar(x: torch.Tensor) -> torch.Tensor:

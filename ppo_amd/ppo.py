@@ -648,6 +648,7 @@ class PPO:
                       and actions.dtype == torch.int32)
         fused_gather = (dev.type == "cuda" and actions.dtype in (torch.int32, torch.float32)
                         and states.dtype == torch.float32)
+        self.last_paths = {"fused_head": bool(fused_head), "fused_gather": bool(fused_gather)}
         for _epoch in range(num_epochs):
             perm = torch.randperm(data_size, device=dev)       # reference :575-576 (np.random.shuffle)
             for start in range(0, data_size, local_batch):

@@ -40,6 +40,20 @@ def test_gather_equals_fancy_indexing(state_shape, act_shape, act_dtype, M, B):
     _case(M, B, state_shape, act_shape, act_dtype, seed=M + B)
 
 
+@pytest.mark.parametrize("state_shape", [(84, 84, 4), (8, 4), (33,), (9, 4)])
+def test_wide_observation_rows(state_shape):
+    """Image observations (BASELINE configs[3]: 84 x 84 x 4 frames): rows of >= 32 words that are
+    16-byte granular move through the wide-row kernel; 33-word rows stay on the per-sample path."""
+    _case(300, 170, state_shape, (), np.int32, seed=len(state_shape))
+    _case(300, 170, state_shape, (), np.int32, seed=7, negative=True)
+    from ppo_amd import ops
+    M = 6
+    z = torch.zeros(M, device="cuda")
+    args = (torch.zeros(M, *state_shape, device="cuda"), torch.zeros(M, dtype=torch.int32, device="cuda"), z, z, z)
+    with pytest.raises(IndexError):
+        ops.minibatch_gather(torch.tensor([2, 6], device="cuda"), *args, check_index=True)
+
+
 def test_negative_indices_wrap_and_out_of_range_raises():
     from ppo_amd import ops
     _case(500, 200, (4,), (), np.int32, seed=1, negative=True)
