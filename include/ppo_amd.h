@@ -43,7 +43,7 @@ extern "C" {
 #define PPO_NET_F16_SPLIT 1  /* v_mfma_f32_32x32x16_f16 on two-piece f16 splits of both operands
                                 (22 significant bits per operand, f32 accumulate): ~1.9x faster.
                                 As accurate as f32 unless the backbone weights are tiny: see
-                                split_margin of ppo_rollout_pack_params */
+                                split_diag of ppo_rollout_pack_params */
 
 int ppo_abi_version(void);
 
@@ -228,19 +228,22 @@ size_t ppo_rollout_param_floats(int kind, int joint, int net_mode);
  *   kind       fixes obs (4 / 6) and A (2 / 3);  joint != 0: va_* are ignored (may be NULL)
  *   net_mode   PPO_NET_F32 or PPO_NET_F16_SPLIT (the layout differs)
  *   params_out ppo_rollout_param_floats(kind, joint, net_mode) floats
- *   split_margin  device f32[1] or NULL: how far this parameter set is from the point where
- *              PPO_NET_F16_SPLIT loses accuracy against f32.  The split's low piece of a value below
- *              2^-3 is an f16 subnormal (absolute error 2^-25); the margin is the minimum, over the
- *              backbone weight tensors, of 8 sum|w'| / #{|w'| < 2^-3} with w' = 2 log2(e) w, i.e. the
- *              ratio of the mode's inherent 2^-22 relative error to that floor for inputs of equal
- *              size.  Use the split kernels for margins >= 4 (ppo_amd.ops.SPLIT_MARGIN_MIN; a
- *              default-initialised or trained network sits at 15-20), PPO_NET_F32 below.
+ *   split_diag device f32[3] or NULL: what decides whether PPO_NET_F16_SPLIT is as accurate as f32
+ *              for this parameter set (w' = 2 log2(e) w is the value the split kernels split):
+ *              [0] min over the backbone weight tensors of 8 sum|w'| / #{|w'| < 2^-3}: the ratio of the
+ *                  mode's inherent 2^-22 relative error to the 2^-25 absolute floor of the low pieces
+ *                  of small weights (f16 subnormals), for inputs of equal size;
+ *              [1], [2] root-mean-square row norm of w' of the first / second backbone layer (max
+ *                  over the backbones): the size of the pre-activations, where a 22-bit product is
+ *                  less accurate than an f32 one.
+ *              ppo_amd.ops.split_ok() holds the measured thresholds ([2] <= 8.5 is the one that
+ *              matters: 2x the reference's orthogonal initialisation); use PPO_NET_F32 outside them.
  */
 int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w1, const float *pi_b1,
                             const float *pi_w2, const float *pi_b2, const float *va_w1,
                             const float *va_b1, const float *va_w2, const float *va_b2,
                             const float *policy_w, const float *policy_b, const float *critic_w,
-                            const float *critic_b, float *params_out, float *split_margin,
+                            const float *critic_b, float *params_out, float *split_diag,
                             void *stream);
 
 /*

@@ -6,14 +6,21 @@
 // (row-major [out, in] weights): it runs right behind optimizer.step() in the update, so a rollout
 // never waits for a host-built gather plan (round 1: ~0.12 ms of small launches per update).
 //
-// A final block measures whether PPO_NET_F16_SPLIT is as accurate as f32 for THIS parameter set.
-// The split keeps x = hi + lo with two f16 pieces: 22 significant bits when |x| >= 2^-3, but the low
-// piece of a smaller value is an f16 subnormal, i.e. an ABSOLUTE error of 2^-25.  For a weight
-// tensor the floor costs sum_{|w'| < 2^-3} 2^-25 |x_k| against the mode's inherent 2^-22 sum |w' x_k|;
-// split_margin = min over the backbone weight tensors of 8 sum |w'| / #{|w'| < 2^-3}
-// (w' = 2 log2(e) w, the value that is split) is the ratio of the two for inputs of equal size:
-// >= 1 means the floor is below the inherent error.  ppo_amd.ops picks the split kernels only for
-// margins well above that (tests/test_gpu_net_precision.py calibrates and pins the threshold).
+// A final block measures what decides whether PPO_NET_F16_SPLIT is as accurate as f32 for THIS
+// parameter set (split_diag, three floats; w' = 2 log2(e) w is the value that is split):
+//   [0] floor margin: the split keeps x = hi + lo in two f16 pieces, 22 significant bits, but the low
+//       piece of a value below 2^-3 is an f16 subnormal, an ABSOLUTE error of 2^-25.  For a weight
+//       tensor that floor costs sum_{|w'| < 2^-3} 2^-25 |x_k| against the mode's inherent
+//       2^-22 sum |w' x_k|; [0] = min over the backbone weight tensors of 8 sum |w'| / #{|w'| < 2^-3},
+//       the ratio of the two for inputs of equal size.  Measured (profiles/r02_net_precision.txt):
+//       harmless down to 3e-4 -- with observations bounded by ~30 the floor stays below the
+//       absolute error of the kernel's own tanh (2^-23), which bounds both network modes.
+//   [1], [2] root-mean-square row norm of w' of the first / second backbone layer (max over the
+//       backbones): the size of the pre-activations.  A 22-bit product is ~3x less accurate than an
+//       f32 one; that shows in the outputs once the pre-activations are large enough for their
+//       rounding error to exceed the tanh / output rounding floor, i.e. for LARGE weights.
+// ppo_amd.ops.split_ok() turns the three numbers into the decision (thresholds calibrated and pinned
+// by tests/test_gpu_net_precision.py).
 #include "common.h"
 #include "net_layout.h"
 
@@ -32,7 +39,7 @@ struct PackArgs {
     Backbone pi, va;
     const float *policy_w, *policy_b, *critic_w, *critic_b;   // [A, 64], [A], [1, 64], [1]
     float *out;
-    float *split_margin;              // or NULL
+    float *split_diag;                // f32[3] or NULL
     int obs, A, joint, net_mode;
     int bb_words, total_words;
 };
@@ -109,41 +116,49 @@ __device__ float head_word(const PackArgs &a, int k)
     return j < a.A ? a.policy_w[j * H + u] : 0.0f;
 }
 
-// sum |w'| and #{|w'| < 2^-3} over n weights (block-wide); every thread returns the block totals
-__device__ void tensor_margin(const float *w, int n, double &sum_abs, double &n_small)
+// sum |w'|, #{|w'| < 2^-3} and sum w'^2 over n weights (block-wide); every thread returns the block totals
+__device__ void tensor_sums(const float *w, int n, double &sum_abs, double &n_small, double &sum_sq)
 {
-    __shared__ double red[2][PACK_BLOCK / 64];
-    double s = 0.0, c = 0.0;
+    __shared__ double red[3][PACK_BLOCK / 64];
+    double s = 0.0, c = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < n; i += PACK_BLOCK) {
         const double v = fabs((double)w[i] * TANH_SCALE);
         s += v;
         c += v < 0.125 ? 1.0 : 0.0;
+        q += v * v;
     }
     s = wave_sum(s);
     c = wave_sum(c);
+    q = wave_sum(q);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = c; }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = c; red[2][threadIdx.x >> 6] = q; }
     __syncthreads();
-    sum_abs = 0.0; n_small = 0.0;
-    for (int k = 0; k < PACK_BLOCK / 64; ++k) { sum_abs += red[0][k]; n_small += red[1][k]; }
+    sum_abs = 0.0; n_small = 0.0; sum_sq = 0.0;
+    for (int k = 0; k < PACK_BLOCK / 64; ++k) { sum_abs += red[0][k]; n_small += red[1][k]; sum_sq += red[2][k]; }
 }
 
 __global__ void __launch_bounds__(PACK_BLOCK) k_pack_params(PackArgs a)
 {
     const int pack_blocks = (a.total_words + PACK_BLOCK - 1) / PACK_BLOCK;
     if ((int)blockIdx.x == pack_blocks) {              // the extra block: split-mode margin of this parameter set
-        if (!a.split_margin) return;
-        double margin = 1e30;
+        if (!a.split_diag) return;
+        double margin = 1e30, g1 = 0.0, g2 = 0.0;
         const int nb = a.joint ? 1 : 2;
         for (int q = 0; q < nb; ++q) {
             const Backbone &b = q == 0 ? a.pi : a.va;
-            double s, c;
-            tensor_margin(b.w1, H * a.obs, s, c);
+            double s, c, sq;
+            tensor_sums(b.w1, H * a.obs, s, c, sq);
             if (c > 0.0) margin = fmin(margin, 8.0 * s / c);
-            tensor_margin(b.w2, H * H, s, c);
+            g1 = fmax(g1, sqrt(sq / H));                  // rms over the 64 rows of the row 2-norm
+            tensor_sums(b.w2, H * H, s, c, sq);
             if (c > 0.0) margin = fmin(margin, 8.0 * s / c);
+            g2 = fmax(g2, sqrt(sq / H));
         }
-        if (threadIdx.x == 0) *a.split_margin = (float)margin;
+        if (threadIdx.x == 0) {
+            a.split_diag[0] = (float)margin;
+            a.split_diag[1] = (float)g1;
+            a.split_diag[2] = (float)g2;
+        }
         return;
     }
     const int k = blockIdx.x * PACK_BLOCK + threadIdx.x;
@@ -167,7 +182,7 @@ extern "C" {
 int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w1, const float *pi_b1,
                             const float *pi_w2, const float *pi_b2, const float *va_w1, const float *va_b1,
                             const float *va_w2, const float *va_b2, const float *policy_w, const float *policy_b,
-                            const float *critic_w, const float *critic_b, float *params_out, float *split_margin,
+                            const float *critic_w, const float *critic_b, float *params_out, float *split_diag,
                             void *stream)
 {
     const int obs = ppo_env_obs_dim(kind);
@@ -179,7 +194,7 @@ int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w
     a.pi = Backbone{pi_w1, pi_b1, pi_w2, pi_b2};
     a.va = Backbone{va_w1, va_b1, va_w2, va_b2};
     a.policy_w = policy_w; a.policy_b = policy_b; a.critic_w = critic_w; a.critic_b = critic_b;
-    a.out = params_out; a.split_margin = split_margin;
+    a.out = params_out; a.split_diag = split_diag;
     a.obs = obs; a.A = kind == PPO_ENV_CARTPOLE ? 2 : 3; a.joint = joint ? 1 : 0; a.net_mode = net_mode;
     a.bb_words = net_mode == PPO_NET_F32 ? backbone_floats(obs) : BB16_WORDS;
     a.total_words = a.bb_words * (joint ? 1 : 2) + HEAD_FLOATS;

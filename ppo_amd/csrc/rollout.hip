@@ -288,7 +288,14 @@ __device__ __forceinline__ f32x16 mfma16(const Frag16 &a, const Frag16 &b, f32x1
 // the two residuals into v_pk_fma_f32 and converts separately: 5 instructions instead of 3).
 __device__ __forceinline__ void split2(float a0, float a1, uint32_t &hi, uint32_t &lo)
 {
+#ifdef PPO_SPLIT_HI_RTZ
     hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+#else
+    // round to nearest (v_cvt_pk_f16_f32, new in gfx950): the residual is at most half an f16 ulp, so
+    // the low piece ends one bit further down than with v_cvt_pkrtz -- same instruction count
+    using h2 = __attribute__((ext_vector_type(2))) _Float16;
+    hi = __builtin_bit_cast(uint32_t, h2{(_Float16)a0, (_Float16)a1});
+#endif
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
 }

@@ -306,10 +306,19 @@ def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int
 
 # --------------------------------------------------------------------------- fused rollout
 NET_F32, NET_F16_SPLIT, NET_AUTO = 0, 1, 2   # include/ppo_amd.h: PPO_NET_F32, PPO_NET_F16_SPLIT; AUTO is resolved here
-# NET_AUTO: the split kernels run only if ppo_rollout_pack_params' split_margin of the parameter set is
-# at least this (pack.hip: >= 1 means the f16-subnormal floor of small weights is below the mode's
-# inherent 2^-22 relative error; the value is calibrated by tests/test_gpu_net_precision.py)
-SPLIT_MARGIN_MIN = 4.0
+# NET_AUTO: the split kernels run only for parameter sets inside these limits of
+# ppo_rollout_pack_params' split_diag (pack.hip says what the three numbers are;
+# tests/test_gpu_net_precision.py pins the limits against a float64 forward and PyTorch's f32 one)
+SPLIT_FLOOR_MARGIN_MIN = 1e-4   # measured harmless down to 3e-4 (the kernel's own tanh error is larger)
+SPLIT_ROWNORM1_MAX = 4.0        # rms row norm of 2 log2(e) W1: 1.0 (CartPole) / 1.25 (Acrobot) at initialisation
+SPLIT_ROWNORM2_MAX = 8.5        # ... of 2 log2(e) W2: 4.08 at the reference's orthogonal(sqrt 2) initialisation
+
+
+def split_ok(diag) -> bool:
+    """The AUTO decision from the three host floats of split_diag."""
+    return bool(diag[0] >= SPLIT_FLOOR_MARGIN_MIN and diag[1] <= SPLIT_ROWNORM1_MAX and diag[2] <= SPLIT_ROWNORM2_MAX)
+
+
 _KIND_OF_OBS = {4: 0, 6: 1}
 
 
@@ -318,10 +327,10 @@ def rollout_param_floats(kind: int, joint, net_mode: int) -> int:
 
 
 def pack_dense_agent(agent, net_mode: int = NET_F32, out: torch.Tensor | None = None,
-                     margin_out: torch.Tensor | None = None) -> torch.Tensor:
+                     diag_out: torch.Tensor | None = None) -> torch.Tensor:
     """ppo_rollout_pack_params: the dense Agent's nn.Linear tensors -> the layout k_rollout reads, one
-    launch, no host work beyond the call.  net_mode is NET_F32 or NET_F16_SPLIT; margin_out (device
-    f32[1]) receives the split-mode margin of this parameter set."""
+    launch, no host work beyond the call.  net_mode is NET_F32 or NET_F16_SPLIT; diag_out (device
+    f32[3]) receives split_diag, the accuracy indicators of the split mode for this parameter set."""
     lib = _lib.load()
     assert net_mode in (NET_F32, NET_F16_SPLIT)
     pi = agent.pi_backbone
@@ -345,20 +354,20 @@ def pack_dense_agent(agent, net_mode: int = NET_F32, out: torch.Tensor | None = 
         out = torch.empty(n, dtype=torch.float32, device=w1.device)
     assert out.numel() == n and out.dtype == torch.float32 and out.is_cuda
     rc = lib.ppo_rollout_pack_params(kind, int(joint), int(net_mode), *[_ptr(t) for t in tensors], _ptr(out),
-                                     _ptr(margin_out), _stream())
+                                     _ptr(diag_out), _stream())
     _lib.check(rc, "ppo_rollout_pack_params")
     return out
 
 
 def resolve_net_mode(agent, net_mode: int):
     """(params, mode actually used, split_ok or None) for a requested mode.  NET_AUTO packs for the
-    split kernels, reads the margin back (one small device->host copy) and falls back to the exact-f32
-    layout when the parameter set fails it."""
+    split kernels, reads split_diag back (one small device->host copy) and falls back to the exact-f32
+    layout when the parameter set is outside the split mode's limits."""
     if net_mode != NET_AUTO:
         return pack_dense_agent(agent, net_mode), net_mode, None
-    margin = torch.empty(1, dtype=torch.float32, device=agent.policy.weight.device)
-    params = pack_dense_agent(agent, NET_F16_SPLIT, margin_out=margin)
-    ok = float(margin.item()) >= SPLIT_MARGIN_MIN
+    diag = torch.empty(3, dtype=torch.float32, device=agent.policy.weight.device)
+    params = pack_dense_agent(agent, NET_F16_SPLIT, diag_out=diag)
+    ok = split_ok(diag.tolist())
     if ok:
         return params, NET_F16_SPLIT, True
     return pack_dense_agent(agent, NET_F32), NET_F32, False

@@ -204,7 +204,7 @@ class SyncVecEnv:
         # how the whole-rollout kernel multiplies inside the network (include/ppo_amd.h): exact f32
         # MFMA products (ops.NET_F32), f16 MFMAs on two-piece splits (ops.NET_F16_SPLIT, ~1.9x faster,
         # 22 bits per operand), or -- the default -- the split kernels whenever the pack kernel's
-        # split_margin says they are as accurate as f32 for the current parameters, f32 otherwise
+        # split_diag says they are as accurate as f32 for the current parameters, f32 otherwise
         # (ops.NET_AUTO).  PPO_AMD_NET = auto | f32 | f16_split.
         self.net_mode = {"auto": ops.NET_AUTO, "f32": ops.NET_F32, "f16_split": ops.NET_F16_SPLIT}[
             os.environ.get("PPO_AMD_NET", "auto")]
@@ -361,33 +361,33 @@ class SyncVecEnv:
         """Queue the pack kernel(s) for the current parameters if they changed since the last pack
         (torch bumps a tensor's _version on every in-place update, i.e. on every optimiser step); no
         host synchronisation.  PPO.train_step calls this right behind the last optimizer.step() of an
-        update, so that the next rollout starts with its parameters packed.  Returns the device f32[1]
-        split margin still to be read (ops.NET_AUTO), else None."""
+        update, so that the next rollout starts with its parameters packed.  Returns the device f32[3]
+        split_diag still to be read (ops.NET_AUTO), else None."""
         key = (self.net_mode,) + tuple((id(p), p._version) for p in self.agent.parameters())
         pk = self._pack
         if pk is not None and pk["key"] == key:
-            return pk["margin"] if pk["ok"] is None else None
+            return pk["diag"] if pk["ok"] is None else None
         if pk is None or pk["mode"] != self.net_mode:
-            pk = self._pack = {"mode": self.net_mode, "bufs": {}, "margin": None}
+            pk = self._pack = {"mode": self.net_mode, "bufs": {}, "diag": None}
             if self.net_mode == ops.NET_AUTO:
-                pk["margin"] = torch.empty(1, dtype=torch.float32, device=self.kdev)
+                pk["diag"] = torch.empty(3, dtype=torch.float32, device=self.kdev)
         pk["key"] = key
         modes = (ops.NET_F16_SPLIT, ops.NET_F32) if self.net_mode == ops.NET_AUTO else (self.net_mode,)
         for m in modes:                                    # AUTO: both layouts (two 5 us launches), decided below
             pk["bufs"][m] = ops.pack_dense_agent(self.agent, m, out=pk["bufs"].get(m),
-                                                 margin_out=pk["margin"] if m == ops.NET_F16_SPLIT else None)
+                                                 diag_out=pk["diag"] if m == ops.NET_F16_SPLIT else None)
         pk["ok"] = None if self.net_mode == ops.NET_AUTO else True
-        return pk["margin"]
+        return pk["diag"]
 
-    def note_split_margin(self, margin: float):
-        """The host value of prepack()'s margin (read by the caller together with its other scalars)."""
-        self._pack["ok"] = bool(margin >= ops.SPLIT_MARGIN_MIN)
+    def note_split_diag(self, diag):
+        """The host values of prepack()'s split_diag (read by the caller together with its other scalars)."""
+        self._pack["ok"] = ops.split_ok(diag)
 
     def _net(self):
         """(packed parameters, network mode) for the next whole-rollout launch."""
         pending = self.prepack()
         if pending is not None:                            # not read by the caller: one small device->host copy
-            self.note_split_margin(float(pending.item()))
+            self.note_split_diag(pending.tolist())
         pk = self._pack
         if self.net_mode != ops.NET_AUTO:
             return pk["bufs"][self.net_mode], self.net_mode
@@ -705,15 +705,15 @@ class PPO:
                 break
         # the next rollout's parameters are packed here, right behind the last optimizer.step(): the
         # rollout bracket of the next update starts with a kernel launch, not with host-side packing
-        margin = ve.prepack() if (ve.native and ve.fused_rollout and dev.type == "cuda") else None
+        diag = ve.prepack() if (ve.native and ve.fused_rollout and dev.type == "cuda") else None
         # one device->host copy for every scalar of this update (it is also the update's final sync)
         scalars = [policy_loss.detach().to(dev), critic_loss.detach().to(dev), entropy.detach().to(dev),
                    kl_div.detach().to(dev), clip_sum]
-        if margin is not None:
-            scalars.append(margin[0].to(dev))
+        if diag is not None:
+            scalars += [diag[0].to(dev), diag[1].to(dev), diag[2].to(dev)]
         host = torch.stack([s.to(torch.float32).reshape(()) for s in scalars]).cpu().tolist()
-        if margin is not None:
-            ve.note_split_margin(host[5])
+        if diag is not None:
+            ve.note_split_diag(host[5:8])
         updates_time = ppo_dist.max_scalar(time.time() - updates_start)
         self._idle = dev.type == "cuda" and world == 1
         grad_steps_per_sec = grad_steps_done / updates_time

@@ -5,14 +5,22 @@ and observations at their bounds -- PPO_NET_F16_SPLIT, PPO_NET_F32 and PyTorch's
 What it replaces: Agent.get_actions_and_values under no_grad inside the rollout (reference
 src/ppo.py:337, network :124-145, :166-216), which the reference computes in f32.
 
-The f16-split mode keeps 22 significant bits per operand but the low piece of a value below 2^-3
-is an f16 subnormal (absolute error 2^-25), so SMALL weights lose relative precision.  The default
-network mode is therefore "auto": ppo_rollout_pack_params measures, per weight tensor, whether that
-floor stays below the mode's inherent 2^-22 relative error (split_ok) and the split kernels are used
-only then; otherwise the exact-f32 MFMA kernels run.  Asserted here, at every scale:
-  * auto-mode max error <= 1.5 x PyTorch-f32's max error (+ 4 ulp of the output scale), and
-  * <= 1e-5 relative (+ 2e-6) per sample,
-and that auto picks the split kernels for the init-scale / trained-scale networks the benchmark uses.
+The f16-split mode multiplies 22-bit operands (two f16 pieces each, round-to-nearest high piece),
+about 3x less accurate per product than f32.  Measured (tools/net_precision_table.py,
+profiles/r02_net_precision.txt): that is invisible in the outputs while the pre-activations are small
+enough for the rounding of the O(1) hidden activations (f32 ulp of 1.0; the kernel's exp2/rcp tanh has
+an absolute error of 2^-23) to dominate -- backbone weights up to 2x the reference's initialisation --
+and shows beyond (1.8-3x PyTorch's error at 3-30x).  SMALL weights, whose low pieces are f16
+subnormals (absolute error 2^-25), measure the same as the exact-f32 kernels down to 1e-4x.
+The default network mode is therefore "auto": ppo_rollout_pack_params reports the size of the
+backbone weights (split_diag) and the split kernels run only inside the measured limits
+(ops.split_ok); otherwise the exact-f32 MFMA kernels do.  Asserted here, for every parameter scale:
+  * auto-mode max error <= 1.5 x PyTorch-f32's max error + 4 ulp of max(1, output scale) -- the
+    hidden activations are O(1) f32 numbers whatever the size of the outputs --, and
+  * <= 1e-5 relative (+ 2e-6) per sample wherever PyTorch's f32 forward meets that bound itself
+    (everywhere except the saturated 30x networks),
+and that auto picks the split kernels from 1e-4x to 2x the initialisation scale (what the benchmark
+and training run) and the f32 kernels from 3x on.
 """
 import numpy as np
 import pytest
@@ -77,7 +85,7 @@ def _f32_torch(agent, states, actions):
     return v, lp
 
 
-SCALES = [1e-4, 1e-2, 0.25, 1.0, 30.0]
+SCALES = [1e-4, 1e-2, 0.25, 1.0, 2.0, 3.0, 30.0]
 
 
 @pytest.mark.parametrize("joint", [1, 0], ids=["joint", "split"])
@@ -113,6 +121,10 @@ def test_network_error_vs_float64_over_scales(kind, joint):
             v64, lp64 = _f64(agent, states, act)
             vt, lpt = _f32_torch(agent, states, act)
             ev_t, el_t = float((vt.double() - v64).abs().max()), float((lpt.double() - lp64).abs().max())
+            # does PyTorch's own f32 forward meet the per-sample bound here?  (not at 30x: saturated network,
+            # pre-activations in the hundreds, every f32 implementation is off by ~1e-5 absolute)
+            torch_meets = bool(((vt.double() - v64).abs() <= 1e-5 * v64.abs() + 2e-6).all()) and \
+                bool(((lpt.double() - lp64).abs() <= 1e-5 * lp64.abs() + 2e-6).all())
             row = dict(kind=kind, joint=joint, scale=scale, head=head_gain, split_ok=bool(res["auto"][4]),
                        torch_v=ev_t, torch_lp=el_t)
             for name in ("auto", "split", "f32"):
@@ -121,15 +133,17 @@ def test_network_error_vs_float64_over_scales(kind, joint):
             print(row)
             ev, el, v64a, lp64a, split_ok = res["auto"]
             # per sample: 1e-5 relative (+ 2e-6, the f32 summation-order floor the other tests use)
-            assert bool((ev <= 1e-5 * v64a.abs() + 2e-6).all()), row
-            assert bool((el <= 1e-5 * lp64a.abs() + 2e-6).all()), row
-            # against PyTorch's own f32 forward: at most 1.5 x its max error, + 4 ulp of the output scale
-            ulp4_v = 2.0 ** -22 * max(float(v64a.abs().max()), 1e-3)
-            ulp4_l = 2.0 ** -22 * max(float(lp64a.abs().max()), 1e-3)
+            assert torch_meets == (scale <= 3.0), row
+            if torch_meets:
+                assert bool((ev <= 1e-5 * v64a.abs() + 2e-6).all()), row
+                assert bool((el <= 1e-5 * lp64a.abs() + 2e-6).all()), row
+            # against PyTorch's own f32 forward: at most 1.5 x its max error, + 4 ulp of max(1, output scale)
+            ulp4_v = 2.0 ** -22 * max(float(v64a.abs().max()), 1.0)
+            ulp4_l = 2.0 ** -22 * max(float(lp64a.abs().max()), 1.0)
             assert row["auto_v"] <= 1.5 * ev_t + ulp4_v, row
             assert row["auto_lp"] <= 1.5 * el_t + ulp4_l, row
-            if scale >= 0.25:         # the networks the benchmark and training actually run: split kernels
-                assert split_ok, row
+            assert split_ok == (scale <= 2.0), row          # where the split kernels run, and where they do not
             if split_ok:              # wherever auto chose the split kernels, the forced-split figures are the same run
                 assert row["split_v"] == row["auto_v"] and row["split_lp"] == row["auto_lp"]
-    assert any(not r["split_ok"] for r in report)      # and the guard does trip for the tiny-weight networks
+            else:
+                assert row["f32_v"] == row["auto_v"] and row["f32_lp"] == row["auto_lp"]

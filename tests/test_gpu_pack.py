@@ -32,29 +32,30 @@ def test_pack_kernel_equals_the_layout_definition(obs, actions, joint, net_mode)
         assert torch.equal(out.view(torch.int32), want.view(torch.int32))
 
 
-def test_split_margin_follows_its_definition():
+def test_split_diag_follows_its_definition():
     from ppo_amd import ops, spaces
     from ppo_amd.ppo import Agent
     torch.manual_seed(1)
     agent = Agent(spaces.Box(-np.inf, np.inf, (4,)), spaces.Discrete(2), 0, 0, "cuda")
-    margin = torch.empty(1, device="cuda")
+    diag = torch.empty(3, device="cuda")
 
     def want():
-        m = float("inf")
+        m, g = float("inf"), [0.0, 0.0]
         for bb in (agent.pi_backbone, agent.va_backbone):
-            for lin in (bb[0], bb[2]):
+            for layer, lin in enumerate((bb[0], bb[2])):
                 w = (lin.weight.detach().double() * (2.0 * 1.4426950408889634)).abs()
                 small = float((w < 0.125).sum())
                 if small:
                     m = min(m, 8.0 * float(w.sum()) / small)
-        return m
+                g[layer] = max(g[layer], float((w * w).sum(1).mean().sqrt()))
+        return [m] + g
 
-    for scale in (1.0, 0.1, 1e-3):
+    for scale in (1.0, 0.1, 1e-3, 3e4):
         with torch.no_grad():
             agent.va_backbone[2].weight.mul_(scale)
-        ops.pack_dense_agent(agent, ops.NET_F16_SPLIT, margin_out=margin)
-        assert abs(float(margin.item()) - want()) <= 1e-5 * want()
-    assert float(margin.item()) < ops.SPLIT_MARGIN_MIN           # tiny value-backbone weights: auto must pick f32
+        ops.pack_dense_agent(agent, ops.NET_F16_SPLIT, diag_out=diag)
+        assert np.allclose(diag.tolist(), want(), rtol=1e-5)
+    assert diag.tolist()[2] > ops.SPLIT_ROWNORM2_MAX             # large value-backbone weights: auto must pick f32
     _, mode, ok = ops.resolve_net_mode(agent, ops.NET_AUTO)
     assert mode == ops.NET_F32 and ok is False
     torch.manual_seed(2)

@@ -13,13 +13,13 @@ import test_gpu_net_precision as T
 from ppo_amd import Agent, ops
 from ppo_amd.envs import DeviceEnv
 
-print("kind joint scale head | margin | split: v lp | f32 mfma: v lp | torch f32: v lp   (max abs error over 2^18 states)")
+print("kind joint scale head | floor margin, rms row norm W1', W2' | split: v lp | f32 mfma: v lp | torch f32: v lp   (max abs error over 2^18 states)")
 for kind in ("cartpole", "acrobot"):
     gen = torch.Generator(device="cuda").manual_seed(11)
     states = T._states(kind, T.NSTATES, gen)
     probe = DeviceEnv(kind)
     for joint in (1, 0):
-        for scale in (1e-4, 1e-3, 1e-2, 0.05, 0.1, 0.25, 0.5, 1.0, 4.0, 30.0):
+        for scale in (1e-4, 1e-3, 1e-2, 0.1, 0.25, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 30.0):
             for head_gain, bias_amp in ((1.0, 0.0), (60.0, 5.0)):
                 torch.manual_seed(int(scale * 1e4) + int(head_gain))
                 agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
@@ -30,8 +30,9 @@ for kind in ("cartpole", "acrobot"):
                             if bias_amp:
                                 lin.bias.uniform_(-bias_amp, bias_amp)
                     agent.policy.weight.mul_(head_gain)
-                margin = torch.empty(1, device="cuda")
-                ops.pack_dense_agent(agent, ops.NET_F16_SPLIT, margin_out=margin)
+                diag = torch.empty(3, device="cuda")
+                ops.pack_dense_agent(agent, ops.NET_F16_SPLIT, diag_out=diag)
+                dg = diag.tolist()
                 out = []
                 for mode in (ops.NET_F16_SPLIT, ops.NET_F32):
                     v, act, lp, _ = T._kernel_forward(kind, agent, states, mode)
@@ -41,5 +42,5 @@ for kind in ("cartpole", "acrobot"):
                 v64, lp64 = T._f64(agent, states, act)
                 vt, lpt = T._f32_torch(agent, states, act)
                 out += [float((vt.double() - v64).abs().max()), float((lpt.double() - lp64).abs().max())]
-                print(f"{kind:8s} {joint} {scale:7.0e} {head_gain:4.0f} | {float(margin.item()):9.3g} | "
+                print(f"{kind:8s} {joint} {scale:7.1e} {head_gain:4.0f} | {dg[0]:8.3g} {dg[1]:6.2f} {dg[2]:6.2f} | "
                       + " | ".join(f"{out[i]:.2e} {out[i+1]:.2e}" for i in (0, 2, 4)), flush=True)
