@@ -20,8 +20,10 @@
  *   - The entry points declared here keep no state between calls: what a call does depends on
  *     its arguments only (no environment variables, no mode switches).  One host thread per
  *     device (the reference is single-threaded, so no concurrency contract is inherited).
- *     Exception: the private bench hooks listed in INTEGRATION.md (not declared here) keep
- *     process-wide HIP event slots and are for one bench thread only.
+ *     Exceptions, both stated where they are declared: ppo_gae_ragged_noalloc works in a
+ *     per-device scratch array inside the library, and the private bench hooks listed in
+ *     INTEGRATION.md (not declared here) keep process-wide HIP event slots and are for one
+ *     bench thread only.
  */
 #ifndef PPO_AMD_H
 #define PPO_AMD_H
@@ -122,6 +124,28 @@ int ppo_gae_ragged(const float *rewards, const float *values, const float *end_v
                    long E, const int *done, const int *trunc, double gamma, double lam,
                    float *adv, int T, int N, void *workspace, size_t workspace_bytes,
                    int *err_flag, void *stream);
+
+/*
+ * ppo_gae_ragged without a workspace argument and without any allocation.  NO COUNTERPART IN THE
+ * REFERENCE: it exists for callers that cannot call hipMalloc (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid allocation).  Same kernels, same results bit for bit; the
+ * scratch (start index per column + one total per 256 columns) lives in a device array inside the
+ * library, (PPO_GAE_RAGGED_NOALLOC_MAX_N + PPO_GAE_RAGGED_NOALLOC_MAX_N / 256) * 8 bytes = 2.1 MB
+ * per GPU the library runs on, held until the process ends.
+ *   - N > PPO_GAE_RAGGED_NOALLOC_MAX_N is rejected with hipErrorInvalidValue (nothing launched):
+ *     use ppo_gae_ragged with a caller workspace for wider batches.
+ *   - Call it with the device of `stream` current: the first call on a device looks up that
+ *     device's copy of the array (hipGetSymbolAddress; make that first call outside graph capture).
+ *   - Calls on one GPU share that GPU's array: calls that may overlap (different streams, different
+ *     host threads) RACE.  Serialise them, or use ppo_gae_ragged with separate workspaces.
+ *   - Nothing has to be cleared between calls: every scratch element a call reads is written by
+ *     the same call first.
+ * All other arguments, the error flag and the return value as in ppo_gae_ragged.
+ */
+#define PPO_GAE_RAGGED_NOALLOC_MAX_N 262144
+int ppo_gae_ragged_noalloc(const float *rewards, const float *values, const float *end_values,
+                           long E, const int *done, const int *trunc, double gamma, double lam,
+                           float *adv, int T, int N, int *err_flag, void *stream);
 
 /* Bytes of device workspace ppo_adv_stats / ppo_loss_fwd_bwd / ppo_loss_logits_fwd_bwd need for B samples. */
 size_t ppo_loss_workspace_bytes(long B);

@@ -429,6 +429,35 @@ int variant_vec(int variant) { return (variant == 1 || variant == 4 || variant =
 
 }  // namespace
 
+// ---- allocation-free form of ppo_gae_ragged -----------------------------------------------------
+// The ragged scan's only scratch is idx0[N] + one total per 256 columns.  Here it lives in a
+// file-scope device array (one copy per GPU, held until the process ends) instead of a caller
+// workspace, for callers that cannot allocate.  The array's NAME is only a host-side handle: the
+// device address comes from hipGetSymbolAddress, once per device, and is what the kernels receive.
+constexpr int RAGGED_NOALLOC_MAX_N = PPO_GAE_RAGGED_NOALLOC_MAX_N;   // 262144: BASELINE configs[2]'s whole batch; 2.1 MB
+constexpr size_t RAGGED_NOALLOC_BYTES =
+    ((size_t)RAGGED_NOALLOC_MAX_N + (RAGGED_NOALLOC_MAX_N + RAG_BLOCK - 1) / RAG_BLOCK) * sizeof(long);
+static __device__ __align__(256) unsigned char scratch[RAGGED_NOALLOC_BYTES];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static void *g_scratch_ptr[NOALLOC_MAX_DEVICES];  // per device: address of that GPU's copy of `scratch`
+
+static int ragged_scratch(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return (int)hipErrorInvalidDevice;
+    if (!g_scratch_ptr[dev]) {                     // first call on this device, with it current
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return (int)hipErrorInvalidSymbol;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
 extern "C" {
 
 static int gae_dense_launch(const float *rewards, const float *values, const float *end_value_dense,
@@ -522,6 +551,20 @@ int ppo_stream_ceiling(const float *r, const float *v, const float *ev, const in
 size_t ppo_gae_ragged_workspace_bytes(int N)
 {
     return N > 0 ? ((size_t)N + (size_t)((N + RAG_BLOCK - 1) / RAG_BLOCK)) * sizeof(long) : 0;
+}
+
+int ppo_gae_ragged_noalloc(const float *rewards, const float *values, const float *end_values, long E,
+                           const int *done, const int *trunc, double gamma, double lam, float *adv, int T,
+                           int N, int *err_flag, void *stream)
+{
+    PPO_REQUIRE(N <= RAGGED_NOALLOC_MAX_N);        // beyond the scratch array: use ppo_gae_ragged with a workspace
+    void *ws = nullptr;
+    const int rc = ragged_scratch(&ws);
+    if (rc) return rc;
+    // every element of the scratch a launch reads (idx0[0..N), totals[0..ceil(N/256))) is written by
+    // k_ep_counts of the same call first, so nothing has to be cleared between calls
+    return ppo_gae_ragged(rewards, values, end_values, E, done, trunc, gamma, lam, adv, T, N, ws,
+                          RAGGED_NOALLOC_BYTES, err_flag, stream);
 }
 
 int ppo_gae_ragged(const float *rewards, const float *values, const float *end_values, long E,

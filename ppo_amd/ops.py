@@ -76,21 +76,31 @@ def gae_dense(rewards, values, end_value_dense, done_flags, trunc_flags, gamma, 
     return (adv, ret) if want_returns else adv
 
 
-def gae_ragged(rewards, values, end_values, done_flags, trunc_flags, gamma, lam, check_index=True):
-    """ppo_gae_ragged: exact drop-in for PPO.compute_advantages (reference src/ppo.py:452-488)."""
+def gae_ragged(rewards, values, end_values, done_flags, trunc_flags, gamma, lam, check_index=True, noalloc=False,
+               out=None, err=None):
+    """ppo_gae_ragged: exact drop-in for PPO.compute_advantages (reference src/ppo.py:452-488).
+    noalloc=True goes through ppo_gae_ragged_noalloc (scratch inside the library, no workspace); with
+    `out` [T,N] f32 and `err` [1] i32 device tensors supplied and device inputs of the right dtype,
+    that path allocates nothing at all."""
     lib = _lib.load()
     src_dev = rewards.device
     r, v, ev = _dev(rewards, torch.float32), _dev(values, torch.float32), _dev(end_values, torch.float32)
     d, tr = _dev(done_flags, torch.int32), _dev(trunc_flags, torch.int32)
     T, N = r.shape
     assert v.shape == (T, N) and d.shape == (T, N) and tr.shape == (T, N) and ev.dim() == 1
-    adv = torch.empty((T, N), dtype=torch.float32, device=r.device)
-    nws = lib.ppo_gae_ragged_workspace_bytes(N)
-    ws = torch.empty(max(nws, 8), dtype=torch.uint8, device=r.device)
-    err = torch.zeros(1, dtype=torch.int32, device=r.device)
-    rc = lib.ppo_gae_ragged(_ptr(r), _ptr(v), _ptr(ev), ev.numel(), _ptr(d), _ptr(tr), float(gamma), float(lam),
-                            _ptr(adv), T, N, _ptr(ws), ws.numel(), _ptr(err), _stream())
-    _lib.check(rc, "ppo_gae_ragged")
+    adv = out if out is not None else torch.empty((T, N), dtype=torch.float32, device=r.device)
+    if err is None:
+        err = torch.zeros(1, dtype=torch.int32, device=r.device)
+    if noalloc:
+        rc = lib.ppo_gae_ragged_noalloc(_ptr(r), _ptr(v), _ptr(ev), ev.numel(), _ptr(d), _ptr(tr), float(gamma),
+                                        float(lam), _ptr(adv), T, N, _ptr(err), _stream())
+        _lib.check(rc, "ppo_gae_ragged_noalloc")
+    else:
+        nws = lib.ppo_gae_ragged_workspace_bytes(N)
+        ws = torch.empty(max(nws, 8), dtype=torch.uint8, device=r.device)
+        rc = lib.ppo_gae_ragged(_ptr(r), _ptr(v), _ptr(ev), ev.numel(), _ptr(d), _ptr(tr), float(gamma), float(lam),
+                                _ptr(adv), T, N, _ptr(ws), ws.numel(), _ptr(err), _stream())
+        _lib.check(rc, "ppo_gae_ragged")
     if check_index and int(err.item()) != 0:  # torch raises IndexError at src/ppo.py:478
         raise IndexError("index out of range in end_values (done+trunc bookkeeping does not match end_values)")
     return adv if src_dev.type == "cuda" else adv.to(src_dev)
