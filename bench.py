@@ -3,18 +3,34 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch: a T=128-step rollout of the env batch
-(policy forward + action sampling + fused env step/reset kernel per time step), the
-bootstrap-value forward over the terminal observations, and the GAE kernel -- the bracket the
-reference times as `env_steps_per_sec` (reference src/ppo.py:544-560).  Workload = BASELINE.json
-configs[1]: CartPole, N = 65536 envs x T = 128 per GPU.  With --gpus N every rank runs that
-workload on its own envs (weak scaling; the path has no data-path collective -- envs shard by
-batch, and the gradient all-reduce belongs to the update, outside this bracket).
+One "step" = one pass of the hot path over one batch, the bracket the reference times as
+`env_steps_per_sec` (reference src/ppo.py:544-560): a T=128-step rollout of the env batch -- ONE launch
+of the whole-rollout kernel (ppo_rollout_fused: per time step the dense 64-64 tanh policy / value
+network on the matrix cores, Philox action sampling, the fp64 env transition with auto-reset, and, for
+truncated episodes, the bootstrap value of the terminal observation from a second network pass in the
+same kernel) --, the episode-statistics kernels of that rollout (reference :404-417, inside the
+reference's bracket too) and the GAE kernel.  Workload = BASELINE.json configs[1]: CartPole,
+N = 65536 envs x T = 128 per GPU.  With --gpus N every rank runs that workload on its own envs
+(weak scaling; the path has no data-path collective -- envs shard by batch, and the gradient
+all-reduce belongs to the update, outside this bracket).
+
+Network arithmetic: `value` is measured in the library's default mode (ops.NET_AUTO): f16-split MFMA
+products (22-bit operands, f32 accumulate) when ppo_rollout_pack_params' split_diag puts the parameter
+set inside the range where that mode measures as accurate as PyTorch's f32 forward
+(tests/test_gpu_net_precision.py), exact-f32 MFMA products otherwise; the bench's freshly initialised
+policy is inside it.  The same steps with exact f32 products forced are reported beside it
+(`value_with_exact_f32_products`) -- the figure to quote against the reference's f32 arithmetic.
+
+After the timed region the same workload runs through PPO.train_step itself (a few updates, joint and
+split networks, 4 minibatches of T*N/4): `train_step` carries the reference's own three rates
+(src/ppo.py:559-560, :637-639) as the trainer reports them, under --gpus N with the RCCL gradient
+all-reduce in the loop.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the GAE kernel (the HBM-bound kernel the north
-star sets a target for), timed with HIP events on the launch stream inside the timed region.
-`cpu_baseline` is the oracle's serial per-env Python restatement of the reference's CPU path
-(oracle/pyref.py, kind "port"), timed on rank 0 at N=1 on a bounded sample.
+star sets a target for), timed with HIP events on the launch stream inside the timed region;
+`rollout_kernel` describes the step's dominant kernel.  `cpu_baseline` is the oracle's serial per-env
+Python restatement of the reference's CPU path (oracle/pyref.py, kind "port"), timed on rank 0 at N=1
+on a bounded sample, plus the restated torch-CPU GAE / loss loops at the full configs[1] shape.
 """
 import argparse
 import ctypes as C
@@ -44,6 +60,7 @@ def parse():
     p.add_argument("--num-envs", type=int, default=65536, help="envs PER GPU")
     p.add_argument("--rollout-len", type=int, default=128)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-train-step", action="store_true")
     p.add_argument("--cpu-sample-envs", type=int, default=4096)
     p.add_argument("--seed", type=int, default=0)
     return p.parse_args()
@@ -82,8 +99,74 @@ def cpu_baseline(kind, n_envs, T, seed):
                       f"{dt:.1f} s on 1 core; per-env cost is constant, so N=65536 extrapolates linearly"}
 
 
+def cpu_gae_loss_baseline(T, N, seed):
+    """BASELINE.md's GAE / loss CPU microbench at the full configs[1] shape: the reference's torch-CPU
+    loops restated (oracle/pyref.gae_torch = src/ppo.py:468-486; oracle/pyref.losses_torch =
+    :498-525 + autograd backward), default torch threads, synthetic inputs of SURVEY.md 8d."""
+    from oracle import pyref
+    g = torch.Generator().manual_seed(1234)
+    r, v = torch.randn(T, N, generator=g), torch.randn(T, N, generator=g)
+    done = (torch.rand(T, N, generator=g) < 1 / 50).to(torch.int32)
+    trunc = ((torch.rand(T, N, generator=g) < 1 / 500) & (done == 0)).to(torch.int32)
+    trunc[-1] = 1 - done[-1]
+    E = int((done + trunc - done * trunc).sum())
+    ev = torch.randn(E, generator=g)
+    pyref.gae_torch(r[:8], v[:8], ev, done[:8], trunc[:8] * 0, 0.99, 0.95)      # warm the allocator
+    t0 = time.perf_counter()
+    adv = pyref.gae_torch(r, v, ev, done, trunc, 0.99, 0.95)
+    gae_ms = 1e3 * (time.perf_counter() - t0)
+    B = T * N // 4                                                               # one minibatch of four
+    old_lp = -torch.randn(B, generator=g).abs()
+    new_lp = (old_lp + 0.05 * torch.randn(B, generator=g)).requires_grad_(True)
+    old_v = torch.randn(B, generator=g)
+    new_v = torch.randn(B, generator=g).requires_grad_(True)
+    a = adv.flatten()[:B].contiguous()
+    t0 = time.perf_counter()
+    pl, vl, cf, kl = pyref.losses_torch(torch.exp(new_lp - old_lp), new_v, old_v, a, 0.2, norm_adv=1, clip_va_loss=1)
+    (pl + 0.5 * vl).backward()
+    loss_ms = 1e3 * (time.perf_counter() - t0)
+    return {"gae_ms": gae_ms, "gae_shape": [T, N], "loss_fwd_bwd_ms": loss_ms, "loss_batch": B,
+            "torch_threads": torch.get_num_threads()}
+
+
+def train_step_rates(kind, N, T, world, seed, updates=4):
+    """The reference's own bracket: PPO.train_step at this workload (global num_envs = N * world,
+    one epoch of four minibatches), joint and split networks; medians over the updates after the first."""
+    from ppo_amd import PPO
+    from ppo_amd.envs import DeviceEnv
+    out = {}
+    for name, joint in (("joint", 1), ("split", 0)):
+        torch.manual_seed(seed)
+        ppo = PPO(0.99, 0.95, 1, 1, 0, joint, True, seed=seed)
+        rows = []
+        orig = ppo.train_step
+
+        def step(*a, _orig=orig, _ppo=ppo, _rows=rows, **k):
+            r = _orig(*a, **k)
+            _rows.append(dict(_ppo.last_metrics))
+            return r
+
+        ppo.train_step = step
+        ppo.train(lambda: DeviceEnv(kind), num_updates=updates, num_envs=N * world, steps_per_env=T, num_epochs=1,
+                  batch_size=T * N * world // 4, critic_coef=0.5, entropy_coef=0.01, clip_ratio=0.2, max_grad_norm=0.5,
+                  learning_rate=3e-4)
+        med = lambda key: float(np.median([m[key] for m in rows[1:]]))
+        out[name] = {"train_step_env_steps_per_sec": med("utils/env_steps_per_sec"),
+                     "grad_steps_per_sec": med("utils/grad_steps_per_sec"),
+                     "global_steps_per_sec": med("utils/global_steps_per_sec"),
+                     "net_mode_used": {0: "f32", 1: "f16_split"}[ppo.vec_env.net_mode_used]}
+        ppo.vec_env.close()
+        del ppo
+        torch.cuda.empty_cache()
+    out["config"] = f"{updates} updates, medians of the last {updates - 1}; num_epochs 1, batch_size T*N/4 (global), norm_adv 1, clip_va_loss 1"
+    return out
+
+
 def main():
     args = parse()
+    if os.environ.get("PPO_AMD_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PPO_AMD_BENCH_WATCHDOG"]), exit=True)
     from ppo_amd import PPO, Agent, SyncVecEnv, ops, _lib
     lib = _lib.load()
     from ppo_amd import dist as D
@@ -136,13 +219,16 @@ def main():
 
     for _ in range(args.warmup):
         hot_path_step(True)        # same code path as the timed steps, so one-time costs land here
+    ve._flush_stats()
     barrier()
     gae_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         hot_path_step(True)
+    ve._flush_stats()              # the last rollout's episode statistics belong to the bracket too (src/ppo.py:404-417)
     barrier()
     elapsed = time.perf_counter() - t0
+    mode_used = {ops.NET_F32: "f32", ops.NET_F16_SPLIT: "f16_split"}[ve.net_mode_used]
     def max_over_ranks(x):
         if world > 1:
             t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -156,13 +242,15 @@ def main():
     ve.net_mode = ops.NET_F32
     for _ in range(2):
         hot_path_step(False)
+    ve._flush_stats()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         hot_path_step(False)
+    ve._flush_stats()
     barrier()
     elapsed_f32 = max_over_ranks(time.perf_counter() - t0)
-    ve.net_mode = ops.NET_F16_SPLIT
+    ve.net_mode = ops.NET_AUTO
 
     # The rollout kernel alone (it is ~85 % of a step): a few more rollouts with an event pair around
     # the launch, outside the timed region -- an event pair inside it would add barrier packets.
@@ -205,14 +293,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 env physics; f32 network, buffers, GAE (network products: exact two-piece f16 splits of "
-                     "both operands, 22 bits each, f32 accumulate -- measured error equal to PyTorch's f32 forward)",
+            "dtype": "f64 env physics; f32 network, buffers, GAE (network products in the library's auto mode: two-piece "
+                     "f16 splits of both operands, 22 bits each, f32 accumulate, chosen per parameter set only where that "
+                     "measures as accurate as PyTorch's f32 forward -- tests/test_gpu_net_precision.py; exact f32 otherwise)",
             "data": "synthetic",
             "value_with_exact_f32_products": total_steps / elapsed_f32,
             "ms_per_step_with_exact_f32_products": 1e3 * elapsed_f32 / args.steps,
             "config": {"workload": f"{kind} batched stepping + GAE, N={N} envs/GPU x T={T}, dense 64-64 tanh policy "
                                    f"(joint net, f32) inside the whole-rollout kernel, BASELINE configs[1]",
-                       "num_envs_per_gpu": N, "rollout_len": T, "net_mode": "f16_split (PPO_NET_F16_SPLIT)", "parallelism": f"env-sharded x{world}, no data-path collective"},
+                       "num_envs_per_gpu": N, "rollout_len": T, "net_mode": f"auto -> {mode_used}", "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "k_gae (ppo_gae_dense)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes,
@@ -236,6 +325,19 @@ def main():
                     "back-to-back loop after the timed region, median of 6"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, args.cpu_sample_envs, T, args.seed)
+            line["cpu_baseline"].update(cpu_gae_loss_baseline(T, N, args.seed))
+    # the reference's own bracket, through the trainer (every rank takes part: gradient all-reduce)
+    ve.close()
+    del ve
+    torch.cuda.empty_cache()
+    if not args.no_train_step:
+        try:
+            rates = train_step_rates(kind, N, T, world, args.seed)
+        except Exception as e:       # the headline line must not be lost to the extra section
+            rates = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            line["train_step"] = rates
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

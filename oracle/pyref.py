@@ -228,3 +228,24 @@ def gae_torch(rewards, values, end_values, done_flags, trunc_flags, gamma, lam):
         nv = values[t]
         na = adv[t]
     return adv
+
+
+def losses_torch(prob_ratios, curr_values, prev_values, advantages, clip_ratio, norm_adv=1, clip_va_loss=1):
+    """The reference's compute_losses in torch ops (src/ppo.py:498-525), restated; differentiable
+    w.r.t. prob_ratios / curr_values like the original.  Pinned against the reference-run goldens in
+    tests/test_oracle.py."""
+    returns = advantages + prev_values                                             # :498
+    if norm_adv:
+        advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)  # :500-501
+    clipped = torch.clamp(prob_ratios, 1 - clip_ratio, 1 + clip_ratio)             # :503
+    policy_loss = -torch.minimum(prob_ratios * advantages, clipped * advantages).mean()   # :504-508
+    if clip_va_loss:                                                               # :512-516
+        sq = (returns - curr_values) ** 2
+        vc = torch.clamp(curr_values, prev_values - clip_ratio, prev_values + clip_ratio)
+        value_loss = 0.5 * torch.maximum(sq, (returns - vc) ** 2).mean()
+    else:
+        value_loss = 0.5 * ((returns - curr_values) ** 2).mean()                   # :518
+    with torch.no_grad():                                                          # :520-525
+        clip_frac = ((prob_ratios - 1.0).abs() > clip_ratio).float().mean()
+        kl_div = (prob_ratios - 1 - torch.log(prob_ratios)).mean()
+    return policy_loss, value_loss, clip_frac, kl_div

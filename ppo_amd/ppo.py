@@ -627,6 +627,8 @@ class PPO:
         ve.rollout()
         with torch.no_grad():
             advantages = self._rollout_advantages(ve)
+        if ve.native:
+            ve._flush_stats()                      # the reference's rollout() ends with the episode statistics (:404-417)
         _sync()
         rollout_time = ppo_dist.max_scalar(time.time() - rollout_start)   # the job waits for its slowest rank
         env_steps_per_sec = steps_per_env * num_envs * world / rollout_time

@@ -130,6 +130,29 @@ def test_oracle_loss_golden(golden_dir):
         assert _rel(g_ratio, L[p + "g_ratio"]) < 1e-5, f"case {i}"
 
 
+def test_torch_restatement_of_compute_losses_golden(golden_dir):
+    """oracle/pyref.losses_torch (bench.py's CPU loss baseline) against the reference-run goldens,
+    values and autograd gradients."""
+    import torch
+    from oracle import pyref
+    L = np.load(os.path.join(golden_dir, "ref_loss.npz"))
+    for i in range(int(L["n_cases"])):
+        p = f"c{i}_"
+        norm_adv, clip_va, clip = L[p + "cfg"]
+        ratio = torch.from_numpy(L[p + "ratio"]).requires_grad_(True)
+        new_v = torch.from_numpy(L[p + "new_v"]).requires_grad_(True)
+        pl, vl, cf, kl = pyref.losses_torch(ratio, new_v, torch.from_numpy(L[p + "old_v"]), torch.from_numpy(L[p + "adv"]),
+                                            float(clip), int(norm_adv), int(clip_va))
+        ref = L[p + "out4"]
+        got = np.array([float(pl), float(vl), float(cf), float(kl)])
+        if not np.isfinite(ref).all():                       # B = 1 with normalisation: NaN like the reference
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            continue
+        assert np.allclose(got, ref, rtol=1e-6, atol=1e-7), f"case {i}"
+        (pl + vl).backward()
+        assert _rel(ratio.grad.numpy(), L[p + "g_ratio"]) < 1e-5 and _rel(new_v.grad.numpy(), L[p + "g_v"]) < 1e-5
+
+
 # -- Philox ---------------------------------------------------------------------------------------
 def test_oracle_loss_logits_golden(golden_dir):
     """Discrete head restatement (Categorical log_prob / entropy + loss) vs the reference's
