@@ -213,7 +213,7 @@ constexpr int ROLLOUT_BLOCK = 256;  // 4 waves, one per SIMD
 // ---- network mode 0: f32 MFMA, every product an exact f32 FMA --------------------------------
 template <int OBS_, int A_, bool JOINT_> struct NetF32 {
     static constexpr int OBS = OBS_, A = A_, WAVE_ENVS = 64;
-    static constexpr bool JOINT = JOINT_;
+    static constexpr bool JOINT = JOINT_, DIFF = false;
     static constexpr int NB = backbone_floats(OBS);
     static constexpr int S1 = ksteps(OBS), S2 = ksteps(H);
     static constexpr int LDS_WORDS = JOINT ? 1 : NB;
@@ -318,6 +318,13 @@ __device__ __forceinline__ void tanh2_prescaled(float x0, float x1, float &a0, f
     a0 = t[0];
     a1 = t[1];
 }
+__device__ __forceinline__ f32x2 tanh2v_prescaled(float x0, float x1)
+{
+    f32x2 e = {__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1)};
+    e += 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
+}
 
 struct RegW16 {
     Frag16 w1[2][2], w2[4][2][2];
@@ -383,10 +390,13 @@ struct LdsHL {
 // ETILES = 2: the wave's 64 lanes are 64 envs, two 32-column MFMA tiles.  ETILES = 1: lanes 0-31 are
 // 32 envs, one tile, lanes 32-63 only hold the other halves of its MFMA operands (their outputs are
 // meaningless): half the network work per wave, for batches too small to give every SIMD a wave of 64.
-template <int OBS, int A, bool DO_P, bool DO_V, int ETILES, class W, class HLT>
+// NP: policy rows in the head table.  A two-action policy keeps ONE row, the difference of its two
+// logit rows (NetF16::load): softmax and sampling only depend on l1 - l0.
+template <int OBS, int NP, bool DO_P, bool DO_V, int ETILES, class W, class HLT>
 __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w, const HLT &hl, int half,
                                               float (&out)[4])
 {
+    constexpr int A = NP;
     static_assert(OBS < 8, "layer-1 inputs and the bias slot must fit one 8-wide k half");
     // ---- input pieces: (obs, 1.0 for the bias, zeros); env tile e reads them from lane half e
     float in[8];
@@ -417,10 +427,13 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
             }
         }
     }
-    // ---- layer 2 + heads, one 32 x 32 output tile at a time
-    float p[4][2];
+    // ---- layer 2 + heads, one 32 x 32 output tile at a time.  Head dot products accumulate two
+    // hidden units at a time (v_pk_fma_f32: tanh hands its outputs over in register pairs, the head
+    // weights of consecutive units are adjacent in the ds_read_b128 result), even and odd units in
+    // the two halves of the accumulator, added once at the end.
+    f32x2 p2[4][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j][0] = p[j][1] = 0.0f;
+    for (int j = 0; j < 4; ++j) p2[j][0] = p2[j][1] = f32x2{0.0f, 0.0f};
 #pragma unroll
     for (int e = 0; e < ETILES; ++e) {
         // first group of head weights: requested before the MFMA chain, in registers when it ends
@@ -453,24 +466,22 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
                     wc[j] = wn[j];
                     if (g + 1 < 8) wn[j] = hl.get4(j, (g + 1) >> 2, (g + 1) & 3);
                 }
-            float h[4];
-            tanh2_prescaled(m[op][r0], m[op][r0 + 1], h[0], h[1]);
-            tanh2_prescaled(m[op][r0 + 2], m[op][r0 + 3], h[2], h[3]);
+            const f32x2 h01 = tanh2v_prescaled(m[op][r0], m[op][r0 + 1]);
+            const f32x2 h23 = tanh2v_prescaled(m[op][r0 + 2], m[op][r0 + 3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if ((j < A && DO_P) || (j == 3 && DO_V)) {
-                    p[j][e] = __builtin_fmaf(h[0], wc[j].x, p[j][e]);
-                    p[j][e] = __builtin_fmaf(h[1], wc[j].y, p[j][e]);
-                    p[j][e] = __builtin_fmaf(h[2], wc[j].z, p[j][e]);
-                    p[j][e] = __builtin_fmaf(h[3], wc[j].w, p[j][e]);
+                    p2[j][e] = __builtin_elementwise_fma(h01, f32x2{wc[j].x, wc[j].y}, p2[j][e]);
+                    p2[j][e] = __builtin_elementwise_fma(h23, f32x2{wc[j].z, wc[j].w}, p2[j][e]);
                 }
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if ((j < A && DO_P) || (j == 3 && DO_V)) {
-            swap_halves(p[j][0], p[j][1]);
-            out[j] = p[j][0] + p[j][1];
+            float p0 = p2[j][0][0] + p2[j][0][1], p1 = ETILES == 2 ? p2[j][1][0] + p2[j][1][1] : 0.0f;
+            swap_halves(p0, p1);
+            out[j] = p0 + p1;
         }
     }
 }
@@ -478,6 +489,11 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
 template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     static constexpr int OBS = OBS_, A = A_, WAVE_ENVS = 32 * ETILES_;
     static constexpr bool JOINT = JOINT_;
+    // Two actions: only l1 - l0 matters to softmax, log-probs and the sampled action, so the head
+    // table holds the difference row (and bias) in slot 0 -- one policy dot product instead of two;
+    // forward() then returns out[0] = l1 - l0 (bias4[0] = b1 - b0).
+    static constexpr bool DIFF = A_ == 2;
+    static constexpr int NP = DIFF ? 1 : A_;
     static constexpr int HL_WORDS = 4 * 2 * 16 * 64;
     static constexpr int LDS_WORDS = (JOINT ? 0 : BB16_WORDS) + HL_WORDS + 4;
     RegW16 P;
@@ -500,7 +516,9 @@ template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
         }
         for (int k = threadIdx.x; k < HL_WORDS; k += ROLLOUT_BLOCK) {     // k = (jo * 16 + r) * 64 + lane
             const int l = k & 63, r = (k >> 6) & 15, jo = k >> 10;
-            shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = heads[k];
+            float v = heads[k];
+            if (DIFF && (jo >> 1) == 0) v = heads[k + 2 * 16 * 64] - v;   // row 0 <- row 1 - row 0
+            shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = v;
         }
         __syncthreads();                           // the only barrier: waves are independent from here on
         V.p = smem;
@@ -508,12 +526,13 @@ template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
         hs.p = shl + 4 * lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j) bias4[j] = heads[4 * 2 * 16 * 64 + j];
+        if (DIFF) bias4[0] = bias4[1] - bias4[0];
     }
     template <bool DO_P, bool DO_V, bool VNET>
     __device__ __forceinline__ void forward(const float (&obs)[6], float (&out)[4]) const
     {
-        if (VNET) net_forward16<OBS, A, DO_P, DO_V, ETILES_>(obs, V, hs, half, out);
-        else net_forward16<OBS, A, DO_P, DO_V, ETILES_>(obs, P, hs, half, out);
+        if (VNET) net_forward16<OBS, NP, DO_P, DO_V, ETILES_>(obs, V, hs, half, out);
+        else net_forward16<OBS, NP, DO_P, DO_V, ETILES_>(obs, P, hs, half, out);
     }
 };
 
@@ -582,8 +601,13 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
             }
         }
         float lg[A];
+        if constexpr (Net::DIFF) {                 // two actions, logits known up to a shift: (0, l1 - l0)
+            lg[0] = 0.0f;
+            lg[1] = out[0] + net.bias4[0];
+        } else {
 #pragma unroll
-        for (int j = 0; j < A; ++j) lg[j] = out[j] + net.bias4[j];
+            for (int j = 0; j < A; ++j) lg[j] = out[j] + net.bias4[j];
+        }
         const float value = out[3] + net.bias4[3];
 
         int action;

@@ -12,9 +12,11 @@
 // of the valid ring slots (<= 52 MB each at N = 65536); an earlier version materialised +inf-padded
 // key arrays and radix-sorted them (rocPRIM via torch.sort): ~460 us of kernel time per rollout,
 // against ~60 us here.
-//   k_sel_hist<L>  : rings -> LDS histograms -> global histogram(s) of level L
-//   k_sel_scan<L>  : histogram(s) -> bucket and residual rank of every target (one wave per target,
-//                    shuffle scans); the last level writes {running max, p5, p50, p95, median length}
+//   k_sel<L> : rings -> LDS histograms -> global histogram(s) of level L; the workgroup that flushes
+//              last (ticket counter in the workspace) narrows every target to its bucket and residual
+//              rank (one wave per target, shuffle scans); the last level writes {running max, p5, p50,
+//              p95, median length}.  Three launches; level 2 returns at once when level 1 found the
+//              low 10 bits of every wanted key clear (integer-valued returns and lengths).
 #include "common.h"
 
 namespace {
@@ -35,6 +37,9 @@ struct SelState {                 // lives at the head of the workspace
     int nlead_ret, nlead;         // the leaders again as two compact lists (returns from entry 0, lengths from SEL_T_RET):
     uint32_t lprefix[SEL_T];      //   prefix to match,
     int lslot[SEL_T];             //   histogram to count into
+    uint32_t ticket;              // workgroups of the running pass that have flushed their histogram (0 between passes)
+    uint32_t low_bits;            // level 1: OR of the low 10 key bits of every key that matched a wanted prefix
+    int skip2;                    // set by level 1 when low_bits == 0: every wanted key is already known, level 2 returns at once
 };
 
 struct SelWs {
@@ -70,19 +75,186 @@ __device__ __forceinline__ float key2f(uint32_t k)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+__device__ void rank_pair(unsigned long long n, double q, unsigned long long &lo, unsigned long long &hi)
+{
+    const double pos = q * (double)(n - 1);                 // np.percentile, method "linear"
+    lo = (unsigned long long)floor(pos);
+    hi = lo + 1 < n ? lo + 1 : n - 1;
+}
+
+__device__ double lerp_pair(double a, double b, unsigned long long n, double q)
+{
+    const double pos = q * (double)(n - 1);
+    return a + (b - a) * (pos - floor(pos));
+}
+
+// One wave owns one target: lane l sums PER consecutive bins, a shuffle scan gives every lane the
+// count before its bins, and the lane whose bins contain the wanted rank walks them again.  The bins
+// are the workgroup's LDS copy of the finished global histogram (re-read there, not kept in
+// registers: the narrowing runs inside the histogram kernel, whose register budget -- two
+// 1024-thread workgroups per CU -- it must not raise; walking them in global memory instead costs a
+// DRAM latency per bin, 100+ us).  The nine targets are narrowed concurrently by nine waves.
+template <int PER> struct WaveBins {
+    const uint32_t *bins;
+    unsigned long long excl, incl, total;
+    __device__ __forceinline__ void load(const uint32_t *b)
+    {
+        const int lane = threadIdx.x & 63;
+        bins = b + lane * PER;
+        const uint4 *p = reinterpret_cast<const uint4 *>(bins);
+        unsigned long long s = 0;
+#pragma unroll 4
+        for (int k = 0; k < PER / 4; ++k) {
+            const uint4 x = p[k];                        // LDS: ds_read_b128
+            s += (unsigned long long)x.x + x.y + x.z + x.w;
+        }
+        incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        excl = incl - s;
+        total = __shfl(incl, 63, 64);
+    }
+    // bucket holding `rank` (rank < total); rank becomes the residual rank inside that bucket.
+    // The lane whose PER bins hold the rank is found from the scan; its bins are then scanned by the
+    // whole wave again, PER <= 64 bins = one per lane (no serial walk).
+    __device__ __forceinline__ int find(unsigned long long &rank) const
+    {
+        static_assert(PER <= 64, "second-level scan gives one bin to every lane");
+        const int lane = threadIdx.x & 63;
+        const bool here = rank >= excl && rank < incl;
+        const int src = __ffsll((long long)__ballot(here)) - 1;
+        const unsigned long long base = __shfl(excl, src, 64);            // entries before the owning lane's bins
+        const uint32_t *owner = bins + (src - lane) * PER;                // this lane's `bins` is offset by lane * PER
+        const unsigned long long v = lane < PER ? owner[lane] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += up;
+        }
+        const unsigned long long before = base + inc - v;
+        const bool mine = v > 0 && rank >= before && rank < before + v;
+        const int who = __ffsll((long long)__ballot(mine)) - 1;
+        rank = rank - __shfl(before, who, 64);
+        return src * PER + who;
+    }
+};
+
+constexpr int SEL_SWAVES = SEL_T;        // narrowing: one wave per target, the first nine waves of the workgroup
+
+// Narrowing of one level, run by the LAST workgroup of that level's histogram pass to finish (every
+// thread of the workgroup calls it).  stats5 = {running max, p5, p50, p95, median length}; entries
+// keep their previous value (NaN at start) while no episode has finished, like the reference's
+// attributes (src/ppo.py:250-254, :408-417).
+template <int LEVEL> __device__ void sel_narrow(const SelWs &w, const uint32_t *hist, double *stats5)
+{
+    __shared__ unsigned long long s_rank[SEL_T];
+    __shared__ uint32_t s_prefix[SEL_T];
+    __shared__ unsigned long long s_n;
+    SelState *st = w.st;
+    const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;   // waves 0..8: this wave's target
+    const bool worker = t < SEL_SWAVES;
+    unsigned long long n = 0, rank = 0;
+    uint32_t prefix = 0;
+    if (LEVEL == 0) {
+        if (worker) {
+            WaveBins<SEL_B0 / 64> wb;
+            wb.load(hist + (t < SEL_T_RET ? 0 : SEL_B0));
+            n = wb.total;                                        // same for returns and lengths
+            if (n > 0) {
+                unsigned long long lo, hi;
+                rank_pair(n, t < 2 ? 0.05 : (t < 4 || t >= SEL_T_RET ? 0.50 : 0.95), lo, hi);
+                const bool upper = t < 6 ? (t & 1) : (t == 8);   // targets come in (lower, upper) pairs
+                rank = t == 6 ? n - 1 : (upper ? hi : lo);
+                prefix = (uint32_t)wb.find(rank);
+            }
+            if (threadIdx.x == 0) s_n = n;
+        }
+    } else {
+        n = st->n;                                               // > 0: the pass returns at once otherwise
+        if (worker) {
+            WaveBins<SEL_B1 / 64> wb;
+            wb.load(hist + st->slot[t] * SEL_B1);
+            rank = st->rank[t];
+            prefix = (st->prefix[t] << 10) | (uint32_t)wb.find(rank);
+        }
+        if (threadIdx.x == 0) s_n = n;
+    }
+    if (worker && lane == 0) { s_rank[t] = rank; s_prefix[t] = prefix; }
+    __syncthreads();
+    n = s_n;
+    if (n == 0) {                                                // uniform: nothing finished yet (level 0 only)
+        if (threadIdx.x == 0) { st->n = 0; st->low_bits = 0u; st->skip2 = 0; }
+        return;
+    }
+    // Level 1 ends the selection when every key that matched a wanted 12-bit prefix has its low 10 bits
+    // clear (integer-valued returns and lengths -- CartPole, Acrobot: always): the 22 bits known now
+    // are the whole key, and level 2 returns at once.
+    const bool last = LEVEL == 2 ||
+                      (LEVEL == 1 && __hip_atomic_load(&st->low_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);
+    // Histograms are cleared here for the next call as soon as they have been consumed (level 1:
+    // hist0, read by level 0's narrowing; the last level: hist1, and hist2 if level 2 filled it), so
+    // that a call finds the workspace zeroed and leaves it zeroed without a memset launch.
+    if (LEVEL == 1) {
+        for (int k = threadIdx.x; k < 2 * SEL_B0; k += SEL_HBLOCK) w.hist0[k] = 0u;
+    }
+    if (LEVEL >= 1 && last) {
+        for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_HBLOCK) w.hist1[k] = 0u;
+    }
+    if (LEVEL == 2) {
+        for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_HBLOCK) w.hist2[k] = 0u;
+    }
+    if (threadIdx.x != 0) return;
+    if (LEVEL == 0) __hip_atomic_store(&st->low_bits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LEVEL == 1) st->skip2 = last ? 1 : 0;
+    if (!last) {                                             // targets with equal prefixes share a histogram
+        st->n = n;
+        for (int u = 0; u < SEL_T; ++u) {
+            int sl = u;
+            for (int q = (u < SEL_T_RET ? 0 : SEL_T_RET); q < u; ++q)
+                if (s_prefix[q] == s_prefix[u]) { sl = q; break; }
+            st->slot[u] = sl;
+            st->leader[u] = sl == u;
+            st->rank[u] = s_rank[u];
+            st->prefix[u] = s_prefix[u];
+        }
+        int nr = 0, nl = 0;                                  // returns' leaders from entry 0, lengths' from SEL_T_RET
+        for (int u = 0; u < SEL_T; ++u) {
+            if (!st->leader[u]) continue;
+            const int at = u < SEL_T_RET ? nr++ : SEL_T_RET + nl++;
+            st->lprefix[at] = s_prefix[u];
+            st->lslot[at] = u;
+        }
+        st->nlead_ret = nr;
+        st->nlead = nr + nl;
+    } else {
+        double v[SEL_T];
+        for (int u = 0; u < SEL_T; ++u) v[u] = (double)key2f(LEVEL == 1 ? s_prefix[u] << 10 : s_prefix[u]);
+        if (!(stats5[0] >= v[6])) stats5[0] = v[6];          // also replaces the initial NaN
+        stats5[1] = lerp_pair(v[0], v[1], n, 0.05);
+        stats5[2] = lerp_pair(v[2], v[3], n, 0.50);
+        stats5[3] = lerp_pair(v[4], v[5], n, 0.95);
+        stats5[4] = lerp_pair(v[7], v[8], n, 0.50);
+    }
+}
+
 template <int LEVEL>
-__global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, const int *len_ring, const int *ring_cnt,
-                                                        int ring, int N, SelWs w)
+__global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, const int *len_ring, const int *ring_cnt,
+                                                      int ring, int N, SelWs w, double *stats5)
 {
     constexpr int NH = LEVEL == 0 ? 2 : SEL_T, NB = LEVEL == 0 ? SEL_B0 : SEL_B1;
     constexpr int SHIFT = LEVEL == 0 ? 20 : (LEVEL == 1 ? 10 : 0);     // digit position
     constexpr int PSHIFT = LEVEL == 1 ? 20 : 10;                       // bits below the fixed prefix
     __shared__ uint32_t h[NH * NB];
-    for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK) h[k] = 0u;
+    __shared__ int s_is_last;
     uint32_t lprefix[SEL_T];
     int lslot[SEL_T], nlead_ret = 0, nlead = 0;
     if (LEVEL > 0) {
         if (w.st->n == 0) return;                                      // uniform: nothing finished yet
+        if (LEVEL == 2 && w.st->skip2) return;                         // uniform: level 1 finished the selection
         nlead_ret = __builtin_amdgcn_readfirstlane(w.st->nlead_ret);
         nlead = __builtin_amdgcn_readfirstlane(w.st->nlead);
 #pragma unroll
@@ -91,6 +263,7 @@ __global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, 
             lslot[q] = __builtin_amdgcn_readfirstlane(w.st->lslot[q]);
         }
     }
+    for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK) h[k] = 0u;
     __syncthreads();
     // Flat walk over the N * ring slots: a wave takes 64 SEL_U consecutive slots at a time, lane l
     // the slots l, l + 64, ...; the (ring, index in ring) pair of the first one costs one division,
@@ -103,6 +276,7 @@ __global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, 
     const uint32_t q64 = 64u / uring, r64 = 64u - q64 * uring;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = blockIdx.x * (SEL_HBLOCK / 64) + (threadIdx.x >> 6), nwv = gridDim.x * (SEL_HBLOCK / 64);
+    uint32_t low = 0u;                                                 // level 1: low 10 bits of the keys that matched
     for (uint32_t b = wv * (64u * SEL_U); b < total; b += nwv * (64u * SEL_U)) {
         const uint32_t i0 = b + lane;
         uint32_t n = i0 / uring, k = i0 - n * uring;
@@ -150,8 +324,15 @@ __global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, 
                 // instruction per key kind (their issue rate is what the pass costs beyond its loads)
                 if (act && sr >= 0) atomicAdd(&h[sr * NB + dr], 1u);
                 if (act && sl >= 0) atomicAdd(&h[sl * NB + dl], 1u);
+                if (LEVEL == 1) {
+                    low |= (act && sr >= 0) ? (kr & 1023u) : 0u;
+                    low |= (act && sl >= 0) ? (kl & 1023u) : 0u;
+                }
             }
         }
+    }
+    if (LEVEL == 1) {
+        if (__any(low != 0u) && lane == 0) atomicOr(&w.st->low_bits, 1u);   // device-scope atomic, like the histogram adds
     }
     __syncthreads();
     uint32_t *g = LEVEL == 0 ? w.hist0 : (LEVEL == 1 ? w.hist1 : w.hist2);
@@ -159,151 +340,30 @@ __global__ void __launch_bounds__(SEL_HBLOCK) k_sel_hist(const float *ret_ring, 
         const uint32_t v = h[k];
         if (v) atomicAdd(&g[k], v);       // integer adds: order-independent, deterministic
     }
-}
-
-__device__ void rank_pair(unsigned long long n, double q, unsigned long long &lo, unsigned long long &hi)
-{
-    const double pos = q * (double)(n - 1);                 // np.percentile, method "linear"
-    lo = (unsigned long long)floor(pos);
-    hi = lo + 1 < n ? lo + 1 : n - 1;
-}
-
-__device__ double lerp_pair(double a, double b, unsigned long long n, double q)
-{
-    const double pos = q * (double)(n - 1);
-    return a + (b - a) * (pos - floor(pos));
-}
-
-// One wave owns one target: lane l holds PER consecutive bins, a shuffle scan gives every lane the
-// count before its bins, and the lane whose bins contain the wanted rank walks them.  No LDS, no
-// block barrier: the nine targets are narrowed concurrently by nine waves.
-template <int PER> struct WaveBins {
-    uint32_t v[PER];
-    unsigned long long excl, incl, total;
-    __device__ __forceinline__ void load(const uint32_t *bins)
-    {
-        const int lane = threadIdx.x & 63;
-        const uint4 *p = reinterpret_cast<const uint4 *>(bins + lane * PER);
-        unsigned long long s = 0;
-#pragma unroll
-        for (int k = 0; k < PER / 4; ++k) {
-            const uint4 x = p[k];
-            v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w;
-            s += (unsigned long long)x.x + x.y + x.z + x.w;
-        }
-        incl = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
-        }
-        excl = incl - s;
-        total = __shfl(incl, 63, 64);
-    }
-    // bucket holding `rank` (rank < total); rank becomes the residual rank inside that bucket
-    __device__ __forceinline__ int find(unsigned long long &rank) const
-    {
-        const int lane = threadIdx.x & 63;
-        const bool here = rank >= excl && rank < incl;
-        int b = 0;
-        unsigned long long resid = 0;
-        if (here) {
-            unsigned long long run = excl;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                if (rank >= run && rank < run + v[k]) { b = lane * PER + k; resid = rank - run; }
-                run += v[k];
-            }
-        }
-        const int src = __ffsll((long long)__ballot(here)) - 1;
-        rank = __shfl(resid, src, 64);
-        return __shfl(b, src, 64);
-    }
-};
-
-constexpr int SEL_SBLOCK = 64 * SEL_T;   // scan kernels: one wave per target
-
-// stats5 = {running max, p5, p50, p95, median length}; entries keep their previous value (NaN at
-// start) while no episode has finished, like the reference's attributes (src/ppo.py:250-254, :408-417).
-template <int LEVEL> __global__ void __launch_bounds__(SEL_SBLOCK) k_sel_scan(SelWs w, double *stats5)
-{
-    __shared__ unsigned long long s_rank[SEL_T];
-    __shared__ uint32_t s_prefix[SEL_T];
-    SelState *st = w.st;
-    const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;   // this wave's target
-    unsigned long long n, rank;
-    uint32_t prefix;
-    if (LEVEL == 0) {
-        WaveBins<SEL_B0 / 64> wb;
-        wb.load(w.hist0 + (t < SEL_T_RET ? 0 : SEL_B0));
-        n = wb.total;                                            // same for returns and lengths
-        if (n == 0) {                                            // uniform: nothing finished yet
-            if (threadIdx.x == 0) st->n = 0;
-            return;
-        }
-        unsigned long long lo, hi;
-        rank_pair(n, t < 2 ? 0.05 : (t < 4 || t >= SEL_T_RET ? 0.50 : 0.95), lo, hi);
-        const bool upper = t < 6 ? (t & 1) : (t == 8);           // targets come in (lower, upper) pairs
-        rank = t == 6 ? n - 1 : (upper ? hi : lo);
-        prefix = (uint32_t)wb.find(rank);
-    } else {
-        n = st->n;
-        if (n == 0) return;                                      // nothing was counted: all histograms are still zero
-        // The histograms this level does not read are cleared here for the next call (level 1: hist0,
-        // consumed by level 0's narrowing; level 2: hist1), and level 2 clears its own after the reads
-        // below: a call finds the workspace zeroed and leaves it zeroed, without a memset launch.
-        uint32_t *stale = LEVEL == 1 ? w.hist0 : w.hist1;
-        for (int k = threadIdx.x; k < (LEVEL == 1 ? 2 * SEL_B0 : SEL_T * SEL_B1); k += SEL_SBLOCK) stale[k] = 0u;
-        WaveBins<SEL_B1 / 64> wb;
-        wb.load((LEVEL == 1 ? w.hist1 : w.hist2) + st->slot[t] * SEL_B1);
-        rank = st->rank[t];
-        prefix = (st->prefix[t] << 10) | (uint32_t)wb.find(rank);
-    }
-    if (lane == 0) { s_rank[t] = rank; s_prefix[t] = prefix; }
+    // The workgroup that flushes last narrows the ranks (one launch per level instead of a histogram
+    // and a one-block kernel).  Everything exchanged between workgroups here is a device-scope atomic
+    // (histogram adds, the ticket, low_bits; the last workgroup reads them back with atomic loads), so
+    // no cache has to be written back or invalidated: a device-scope FENCE on this eight-XCD part is an
+    // L2 write-back per workgroup, which made each pass 150 us instead of 17.  Waiting for this lane's
+    // atomics to be acknowledged (vmcnt) orders them before the workgroup's ticket.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
     __syncthreads();
-    if (LEVEL == 2) {
-        for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_SBLOCK) w.hist2[k] = 0u;
-    }
-    if (threadIdx.x != 0) return;
-    if (LEVEL < 2) {                                         // targets with equal prefixes share a histogram
-        st->n = n;
-        for (int u = 0; u < SEL_T; ++u) {
-            int sl = u;
-            for (int q = (u < SEL_T_RET ? 0 : SEL_T_RET); q < u; ++q)
-                if (s_prefix[q] == s_prefix[u]) { sl = q; break; }
-            st->slot[u] = sl;
-            st->leader[u] = sl == u;
-            st->rank[u] = s_rank[u];
-            st->prefix[u] = s_prefix[u];
-        }
-        int nr = 0, nl = 0;                                  // returns' leaders from entry 0, lengths' from SEL_T_RET
-        for (int u = 0; u < SEL_T; ++u) {
-            if (!st->leader[u]) continue;
-            const int at = u < SEL_T_RET ? nr++ : SEL_T_RET + nl++;
-            st->lprefix[at] = s_prefix[u];
-            st->lslot[at] = u;
-        }
-        st->nlead_ret = nr;
-        st->nlead = nr + nl;
-    } else {
-        double v[SEL_T];
-        for (int u = 0; u < SEL_T; ++u) v[u] = (double)key2f(s_prefix[u]);
-        if (!(stats5[0] >= v[6])) stats5[0] = v[6];          // also replaces the initial NaN
-        stats5[1] = lerp_pair(v[0], v[1], n, 0.05);
-        stats5[2] = lerp_pair(v[2], v[3], n, 0.50);
-        stats5[3] = lerp_pair(v[4], v[5], n, 0.95);
-        stats5[4] = lerp_pair(v[7], v[8], n, 0.50);
-    }
+    if (threadIdx.x == 0)
+        s_is_last = __hip_atomic_fetch_add(&w.st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_is_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(&w.st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next pass
+    for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK)  // the finished histogram into this workgroup's LDS
+        h[k] = __hip_atomic_load(&g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    sel_narrow<LEVEL>(w, h, stats5);
 }
 
 template <int LEVEL>
 int sel_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N, const SelWs &w,
               double *stats5, unsigned blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sel_hist<LEVEL>, dim3(blocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w);
-    int rc = ppo_launch_status();
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_sel_scan<LEVEL>, dim3(1), dim3(SEL_SBLOCK), 0, s, w, stats5);
+    hipLaunchKernelGGL(k_sel<LEVEL>, dim3(blocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5);
     return ppo_launch_status();
 }
 
