@@ -231,8 +231,8 @@ int ppo_linear_wgrad(const float *g, const float *x, long B, int M, int K, float
 
 /*
  * Categorical sampling for the rollout's policy step: for each row of logits[N,A]
- * draw an action with Philox4x32-10 keyed (seed; env_base+n, step) and return its
- * log-probability.  Replaces torch.distributions.Categorical(logits).sample() and
+ * draw an action with Philox4x32-10 keyed (seed; env_base+n, step / 4), word step % 4 (one block
+ * serves four consecutive steps of an env), and return its log-probability.  Replaces torch.distributions.Categorical(logits).sample() and
  * .log_prob() at src/ppo.py:186-189,212 inside SyncVecEnv.rollout (:337).
  *   action [N] i32, logp [N] f32.  A <= 32.
  */

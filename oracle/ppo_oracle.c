@@ -307,18 +307,20 @@ void oracle_reset_uniform4(uint64_t seed, uint64_t env_id, uint32_t episode, dou
 
 /* Action-sampling draws of one policy step for envs env_base .. env_base + N - 1 (ours; the
  * reference samples from torch's unseeded global RNG, src/ppo.py:186-189):
- *   key = (seed_lo, seed_hi ^ 0x5bd1e995), counter = (env_lo, env_hi, step_lo, step_hi),
- *   u = (word0 >> 8) * 2^-24 in [0, 1).  The sampled action is the first k with
+ *   key = (seed_lo, seed_hi ^ 0x5bd1e995), counter = (env_lo, env_hi, block_lo, block_hi) with
+ *   block = step / 4: one Philox block serves four consecutive steps, word = step % 4;
+ *   u = (word >> 8) * 2^-24 in [0, 1).  The sampled action is the first k with
  *   u * sum_j exp(l_j - max) < sum_{j<=k} exp(l_j - max)  (inverse CDF over the softmax).   */
 void oracle_sample_uniform_batch(uint64_t seed, uint64_t env_base, uint64_t step, float *u, int N)
 {
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u};
     for (int n = 0; n < N; ++n) {
         uint64_t id = env_base + (uint64_t)n;
-        uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+        uint64_t block = step >> 2;
+        uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), (uint32_t)block, (uint32_t)(block >> 32)};
         uint32_t o[4];
         oracle_philox4x32_10(ctr, key, o);
-        u[n] = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+        u[n] = (float)(o[step & 3] >> 8) * (1.0f / 16777216.0f);
     }
 }
 

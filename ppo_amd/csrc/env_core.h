@@ -337,12 +337,44 @@ __device__ __forceinline__ void store_env(const EnvRegs &e, const EnvArgs &a, si
 // The uniform draw of (seed; env id, policy step): it depends on nothing the network computes, so the
 // whole-rollout kernel makes it before the forward pass, where its ten dependent Philox rounds fill
 // VALU slots in the shadow of the first MFMAs instead of sitting between the logits and the action.
+// One Philox4x32-10 block serves FOUR consecutive policy steps of an env: block = step / 4 (the
+// counter), word = step % 4.  The whole-rollout kernel therefore runs the ten rounds on every fourth
+// step only (SampleDraws below); this function is the definition, used by the per-step kernel.
+__device__ __forceinline__ Philox4 sample_block(uint64_t seed, uint64_t id, uint64_t block)
+{
+    return philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)block, (uint32_t)(block >> 32),
+                         (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
+}
+__device__ __forceinline__ float uniform24(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }  // [0,1)
+
 __device__ __forceinline__ float sample_uniform(uint64_t seed, uint64_t id, uint64_t step)
 {
-    const Philox4 rnd = philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)step, (uint32_t)(step >> 32),
-                                      (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u);
-    return (float)(rnd.v[0] >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+    const Philox4 rnd = sample_block(seed, id, step >> 2);
+    const uint32_t w = (uint32_t)step & 3u;
+    return uniform24(w == 0 ? rnd.v[0] : (w == 1 ? rnd.v[1] : (w == 2 ? rnd.v[2] : rnd.v[3])));
 }
+
+// The same stream, one step after the other: next(step) == sample_uniform(seed, id, step) for
+// consecutive steps.  Holds the unused words of the current block; the ten rounds run when they run
+// out (every fourth step, at a wave-uniform point since all lanes share `step`).
+struct SampleDraws {
+    uint32_t w0, w1, w2;   // words still to hand out, in order
+    __device__ __forceinline__ float next(uint64_t seed, uint64_t id, uint64_t step, bool first)
+    {
+        const uint32_t k = (uint32_t)step & 3u;
+        uint32_t word;
+        if (k == 0 || first) {                       // wave-uniform
+            const Philox4 rnd = sample_block(seed, id, step >> 2);
+            word = k == 0 ? rnd.v[0] : (k == 1 ? rnd.v[1] : (k == 2 ? rnd.v[2] : rnd.v[3]));
+            w0 = k == 0 ? rnd.v[1] : (k == 1 ? rnd.v[2] : rnd.v[3]);
+            w1 = k == 0 ? rnd.v[2] : rnd.v[3];
+            w2 = rnd.v[3];
+        } else {
+            word = w0; w0 = w1; w1 = w2;
+        }
+        return uniform24(word);
+    }
+};
 
 __device__ __forceinline__ void categorical_from_uniform(const float *lg, int A, float u, int &action, float &logp)
 {

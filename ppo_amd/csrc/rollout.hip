@@ -585,11 +585,13 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         if (has) a.ev_dense[(size_t)pend_t * N + n] = ev[3] + net.bias4[3];
         pend_t = -1;
     };
+    SampleDraws draws;
+    draws.w0 = draws.w1 = draws.w2 = 0u;
     for (int t = 0; t < a.T; ++t) {
         StepOut o;
         o.trunc = 0;
         // the step's uniform draw first (see sample_uniform)
-        const float u_draw = sample_uniform(a.env.seed, a.env.env_base + nn, a.sample_step0 + (uint64_t)t);
+        const float u_draw = draws.next(a.env.seed, a.env.env_base + nn, a.sample_step0 + (uint64_t)t, t == 0);
         // ---- backbone(s) + heads (src/ppo.py:126-145, :174-182)
         float out[4] = {0.f, 0.f, 0.f, 0.f};
         if (!(ABLATE(a) & 1)) {
