@@ -328,7 +328,25 @@ __device__ __forceinline__ f32x2 tanh2v_prescaled(float x0, float x1)
 
 struct RegW16 {
     Frag16 w1[2][2], w2[4][2][2];
+#ifdef PPO_B2_IN_LDS
+    // Tried and dropped (-DPPO_B2_IN_LDS): the layer-2 bias (the C operand of each tile's first MFMA)
+    // read from LDS when a tile starts -- 32 registers less to hold for the whole rollout, 119 -> 68
+    // v_accvgpr moves in the loop body, but the reads sit in front of the MFMA chain: 445 -> 462 us.
+    const float *b2s;                              // LDS copy as [op][r / 4][lane][r % 4], offset by 4 lane
+    __device__ __forceinline__ f32x16 bias2(int op) const
+    {
+        f32x16 b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 x = *reinterpret_cast<const float4 *>(b2s + (op * 4 + q) * 256);
+            b[4 * q] = x.x; b[4 * q + 1] = x.y; b[4 * q + 2] = x.z; b[4 * q + 3] = x.w;
+        }
+        return b;
+    }
+#else
     f32x16 b2[2];
+    __device__ __forceinline__ f32x16 bias2(int op) const { return b2[op]; }
+#endif
     __device__ __forceinline__ void load(const float *__restrict__ g, int lane)
     {
         const uint4 *v = reinterpret_cast<const uint4 *>(g);
@@ -348,14 +366,15 @@ struct RegW16 {
                     const uint4 x = v[BB16_W1 / 4 + ((j * 2 + op) * 2 + pc) * 64 + lane];
                     w2[j][op][pc] = Frag16{{x.x, x.y, x.z, x.w}};
                 }
+#ifndef PPO_B2_IN_LDS
 #pragma unroll
         for (int op = 0; op < 2; ++op)
 #pragma unroll
             for (int r = 0; r < 16; ++r) b2[op][r] = g[BB16_W1 + BB16_W2 + (op * 16 + r) * 64 + lane];
+#endif
     }
     __device__ __forceinline__ Frag16 get1(int op, int pc) const { return w1[op][pc]; }
     __device__ __forceinline__ Frag16 get2(int j, int op, int pc) const { return w2[j][op][pc]; }
-    __device__ __forceinline__ f32x16 bias2(int op) const { return b2[op]; }
 };
 struct LdsW16 {
     const float *p;   // LDS copy of one backbone
@@ -495,7 +514,7 @@ template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     static constexpr bool DIFF = A_ == 2;
     static constexpr int NP = DIFF ? 1 : A_;
     static constexpr int HL_WORDS = 4 * 2 * 16 * 64;
-    static constexpr int LDS_WORDS = (JOINT ? 0 : BB16_WORDS) + HL_WORDS + 4;
+    static constexpr int LDS_WORDS = (JOINT ? 0 : BB16_WORDS) + HL_WORDS + BB16_B2 + 4;
     RegW16 P;
     LdsW16 V;
     LdsHL hs;
@@ -520,6 +539,14 @@ template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
             if (DIFF && (jo >> 1) == 0) v = heads[k + 2 * 16 * 64] - v;   // row 0 <- row 1 - row 0
             shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = v;
         }
+#ifdef PPO_B2_IN_LDS
+        float *sb2 = shl + HL_WORDS;               // policy backbone's layer-2 bias, [op][r / 4][lane][r % 4]
+        for (int k = threadIdx.x; k < BB16_B2; k += ROLLOUT_BLOCK) {      // k = (op * 16 + r) * 64 + lane
+            const int l = k & 63, r = (k >> 6) & 15, op = k >> 10;
+            sb2[((op * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = params[BB16_W1 + BB16_W2 + k];
+        }
+        P.b2s = sb2 + 4 * lane;
+#endif
         __syncthreads();                           // the only barrier: waves are independent from here on
         V.p = smem;
         V.lane = lane;
