@@ -11,11 +11,13 @@ import torch  # noqa: E402
 
 from ppo_amd import PPO  # noqa: E402
 from ppo_amd import dist as D  # noqa: E402
-from ppo_amd.env_cartpole import train_fn  # noqa: E402
+from ppo_amd.envs import DeviceEnv  # noqa: E402
 
 
 def main():
     out, num_envs, T, batch, updates = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    kind = sys.argv[6] if len(sys.argv) > 6 else "cartpole"
+    train_fn = lambda: DeviceEnv(kind)  # noqa: E731
     D.init_from_env()                       # backend from PPO_AMD_DIST_BACKEND (gloo: both ranks share the one GPU)
     rank, world = D.rank(), D.world_size()
     torch.manual_seed(100 + 7 * rank)       # different init per rank: broadcast_params must equalise

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
-N, T, BATCH, UPDATES = 256, 32, 2048, 3
+T, UPDATES = 32, 3
 
 
 def _free_port():
@@ -33,7 +33,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(out, world):
+def _launch(out, world, kind, N, BATCH):
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -44,7 +44,7 @@ def _launch(out, world):
             env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), PPO_AMD_DIST_BACKEND="gloo")
         env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-        procs.append(subprocess.Popen([sys.executable, "-u", WORKER, out, str(N), str(T), str(BATCH), str(UPDATES)],
+        procs.append(subprocess.Popen([sys.executable, "-u", WORKER, out, str(N), str(T), str(BATCH), str(UPDATES), kind],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -60,11 +60,13 @@ def _launch(out, world):
     return [torch.load(f"{out}.rank{r}", weights_only=True) for r in range(world)]
 
 
-def test_world2_training_equals_the_single_process_run(tmp_path):
+@pytest.mark.parametrize("kind,N,BATCH", [("cartpole", 256, 2048), ("acrobot", 2048, 16384)],
+                         ids=["cartpole_256", "acrobot_2048_sharded_like_configs2"])
+def test_world2_training_equals_the_single_process_run(tmp_path, kind, N, BATCH):
     from ppo_amd import Agent, ops
     from ppo_amd.envs import DeviceEnv
-    r0, r1 = _launch(str(tmp_path / "dp2"), 2)
-    (w1,) = _launch(str(tmp_path / "dp1"), 1)
+    r0, r1 = _launch(str(tmp_path / "dp2"), 2, kind, N, BATCH)
+    (w1,) = _launch(str(tmp_path / "dp1"), 1, kind, N, BATCH)
     assert r0["world"] == 2 and r1["rank"] == 1 and w1["world"] == 1
 
     # broadcast: both ranks start from rank 0's parameters, which are the world-1 run's (same seed)
@@ -88,7 +90,7 @@ def test_world2_training_equals_the_single_process_run(tmp_path):
     assert r0["steps"][0]["idx"].numel() + r1["steps"][0]["idx"].numel() == w1["steps"][0]["idx"].numel() == BATCH
 
     # first minibatch: mean of the ranks' losses == losses of the union minibatch with world-1 state
-    probe = DeviceEnv("cartpole")
+    probe = DeviceEnv(kind)
     agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
     agent.load_state_dict(w1["init"])
     buf = {k: v.cuda() for k, v in w1["buffers"].items()}

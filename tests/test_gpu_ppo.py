@@ -133,13 +133,18 @@ def test_device_rollout_matches_serial_reference_loop(kind, joint, whole, reques
         lp = torch.log_softmax(logits, 1).gather(1, ve.actions.flatten().long()[:, None])[:, 0]
         assert torch.allclose(lp, ve.log_probs.flatten(), rtol=1e-5, atol=2e-6)
         assert torch.allclose(vals, ve.values.flatten(), rtol=1e-5, atol=2e-6)
-        # and the sampled actions are the Philox draw applied to those logits
+        # and the sampled actions are the Philox draw applied to those logits: against the per-step sampler
+        # kernel, and exactly -- outside a 1e-5 band around the CDF boundaries, where an ulp in a logit
+        # may flip the draw -- against the oracle's draw applied to the PyTorch logits in float64
         from ppo_amd import ops
         for t in (0, T // 2, T - 1):
             with torch.no_grad():
                 lg, _ = agent.policy_and_values(ve.states.detach()[t])
             a_ref, _ = ops.categorical_sample(lg, seed, 0, k * T + t)
-            assert (a_ref == ve.actions[t]).float().mean() > 0.98  # an ulp in a logit may flip a boundary draw
+            assert (a_ref == ve.actions[t]).float().mean() > 0.98
+            u = cref.sample_uniform(seed, 0, k * T + t, N)
+            bad, amb = cref.categorical_check(lg.cpu().numpy(), u, ve.actions[t].cpu().numpy())
+            assert bad == 0 and amb <= 2, (t, bad, amb)
         assert int(ref["done"].sum()) > 0 or kind == "acrobot"
 
 
@@ -472,3 +477,49 @@ def test_host_stepped_env_uses_gpu_gae_and_loss(use_gpu):
     ended = (ve.done_flags + ve.trunc_flags) > 0
     assert ve.end_states.shape == (int(ended.sum()), 27) and bool(ended[-1].all())
     assert np.isfinite(ppo.last_metrics["losses/critic_loss"]) and ve.median_ep_length == 17
+
+
+def test_native_both_flags_cell_through_dense_gae():
+    """CartPole falling on the very step that reaches the 500-step limit: gymnasium reports
+    terminated AND truncated, and both flags reach the reference's GAE (src/ppo.py:476-480), where
+    `(1 - terminations)` becomes -1 and the ragged index is decremented by 2.  The whole-rollout
+    kernel emits both flags natively, records the terminal observation once, writes its bootstrap
+    value (trunc != 0), and the trainer's dense GAE follows the reference's (1 - 2) arithmetic on that
+    cell: bit-exact against the oracle, and bit-equal to the reference's ragged form on the same
+    rollout.  (The extra index decrement can only reach an EARLIER truncated cell of the same env,
+    i.e. a second time-limit hit: impossible inside a rollout of T <= 500 steps.)"""
+    from ppo_amd import Agent, SyncVecEnv, ops
+    from ppo_amd.envs import DeviceEnv
+    torch.manual_seed(2)
+    N, T = 256, 16
+    probe = DeviceEnv("cartpole")
+    agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
+    with torch.no_grad():
+        agent.critic.bias.fill_(0.5)
+    ve = SyncVecEnv(lambda: DeviceEnv("cartpole", seed=3), N, T, 0, 0.0, agent, seed=3)
+    # every fourth env: pole at 0.205 rad falling at 3 rad/s -- the next step crosses 12 degrees whatever
+    # the action -- and one step short of the time limit
+    doomed = torch.arange(0, N, 4, device="cuda")
+    ve.batch.state[doomed] = torch.tensor([0.0, 0.0, 0.205, 3.0], dtype=torch.float64, device="cuda")
+    ve.batch.elapsed[doomed] = 499
+    ve.t_states[doomed] = torch.tensor([0.0, 0.0, 0.205, 3.0], device="cuda")
+    ve.rollout()
+    d, tr = ve.done_flags, ve.trunc_flags
+    assert bool((d[0, doomed] == 1).all()) and bool((tr[0, doomed] == 1).all())      # both flags, natively
+    assert int(((d == 1) & (tr == 1)).sum()) == doomed.numel()
+    with torch.no_grad():                                                             # bootstrap value recorded
+        want = agent.get_values(ve._term_obs[0, doomed])
+    assert torch.allclose(ve._ev_dense[0, doomed], want, rtol=1e-5, atol=2e-6)
+    assert float(ve.states.detach()[1, doomed].abs().max()) <= 0.05 + 1e-6            # and the env was reset
+    assert ve.end_states.shape[0] == int(((d + tr) > 0).sum())                        # one terminal observation per cell
+    # dense GAE (what train_step runs) == the oracle's dense restatement of :476-486, bit for bit
+    evz = torch.where(tr > 0, ve._ev_dense, torch.zeros_like(ve._ev_dense))
+    adv = ops.gae_dense(ve.rewards, ve.values, ve._ev_dense, d, tr, 0.99, 0.95)
+    r_np, v_np, d_np, tr_np = (x.cpu().numpy() for x in (ve.rewards, ve.values, d, tr))
+    assert np.array_equal(adv.cpu().numpy(), cref.gae_dense(r_np, v_np, evz.cpu().numpy(), d_np, tr_np, 0.99, 0.95))
+    # ... == the reference's ragged form with the kernel's own bootstrap values in the reference's order
+    end_values = ve._ev_dense.t()[((d + tr) > 0).t()]                                 # actor-major, time-ascending (:401-402)
+    end_values = torch.where((tr.t()[((d + tr) > 0).t()]) > 0, end_values, torch.zeros_like(end_values))
+    ragged = ops.gae_ragged(ve.rewards, ve.values, end_values, d, tr, 0.99, 0.95)
+    assert np.array_equal(ragged.cpu().numpy(), cref.gae_ragged(r_np, v_np, end_values.cpu().numpy(), d_np, tr_np, 0.99, 0.95))
+    assert torch.equal(ragged, adv)

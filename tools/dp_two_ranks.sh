@@ -4,9 +4,9 @@
 set -u
 N=$1; T=$2; B=$3; U=$4; OUT=$5
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 WORLD_SIZE=2 PPO_AMD_DIST_BACKEND=gloo LOCAL_RANK=0
-RANK=0 timeout -k 5 120 python -u -X faulthandler tests/dp_worker.py "$OUT" "$N" "$T" "$B" "$U" > "$OUT.r0.log" 2>&1 &
+RANK=0 timeout -k 5 120 python -u -X faulthandler tests/dp_worker.py "$OUT" "$N" "$T" "$B" "$U" ${6:-cartpole} > "$OUT.r0.log" 2>&1 &
 P0=$!
-RANK=1 timeout -k 5 120 python -u -X faulthandler tests/dp_worker.py "$OUT" "$N" "$T" "$B" "$U" > "$OUT.r1.log" 2>&1 &
+RANK=1 timeout -k 5 120 python -u -X faulthandler tests/dp_worker.py "$OUT" "$N" "$T" "$B" "$U" ${6:-cartpole} > "$OUT.r1.log" 2>&1 &
 P1=$!
 wait $P0; R0=$?
 wait $P1; R1=$?
