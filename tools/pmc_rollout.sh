@@ -3,7 +3,7 @@
 # usage: pmc_rollout.sh <tag> <time_rollout args...>
 tag=$1; shift
 export TMPDIR=/tmp
-d=gpurun_out/r01/pmc_$tag
+d=gpurun_out/${PPO_ROUND:-r02}/pmc_$tag
 mkdir -p $d
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $d/p1 -- python3 tools/time_rollout.py "$@" > $d/p1.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_SCA SQ_INSTS_LDS --output-format csv -d $d/p2 -- python3 tools/time_rollout.py "$@" > $d/p2.log 2>&1 || exit 1

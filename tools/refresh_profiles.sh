@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round evidence in one GPU call: the GPU test suite, the bench line, the same command under
-# rocprofv3 --kernel-trace --stats, and the Acrobot line.  Outputs under gpurun_out/r01/final/.
+# rocprofv3 --kernel-trace --stats, and the Acrobot line.  Outputs under gpurun_out/<round>/final/.
 set -o pipefail
 export TMPDIR=/tmp
-o=gpurun_out/r01/final
+o=gpurun_out/${PPO_ROUND:-r02}/final
 rm -rf $o/prof
 mkdir -p $o
 timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $o/pytest_gpu.txt 2>&1 || { tail -20 $o/pytest_gpu.txt; exit 1; }
