@@ -38,7 +38,7 @@ struct SelState {                 // lives at the head of the workspace
     uint32_t lprefix[SEL_T];      //   prefix to match,
     int lslot[SEL_T];             //   histogram to count into
     uint32_t ticket;              // workgroups of the running pass that have flushed their histogram (0 between passes)
-    uint32_t low_bits;            // level 1: OR of the low 10 key bits of every key that matched a wanted prefix
+    uint32_t low_bits;            // level 1: nonzero if a value that matched a wanted prefix has low float bits set
     int skip2;                    // set by level 1 when low_bits == 0: every wanted key is already known, level 2 returns at once
 };
 
@@ -190,9 +190,9 @@ template <int LEVEL> __device__ void sel_narrow(const SelWs &w, const uint32_t *
         if (threadIdx.x == 0) { st->n = 0; st->low_bits = 0u; st->skip2 = 0; }
         return;
     }
-    // Level 1 ends the selection when every key that matched a wanted 12-bit prefix has its low 10 bits
-    // clear (integer-valued returns and lengths -- CartPole, Acrobot: always): the 22 bits known now
-    // are the whole key, and level 2 returns at once.
+    // Level 1 ends the selection when every value that matched a wanted 12-bit prefix has the low 10
+    // bits of its float pattern clear (integer-valued returns and lengths -- CartPole, Acrobot: always):
+    // the 22 bits known now determine the whole key, and level 2 returns at once.
     const bool last = LEVEL == 2 ||
                       (LEVEL == 1 && __hip_atomic_load(&st->low_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);
     // Histograms are cleared here for the next call as soon as they have been consumed (level 1:
@@ -232,7 +232,13 @@ template <int LEVEL> __device__ void sel_narrow(const SelWs &w, const uint32_t *
         st->nlead = nr + nl;
     } else {
         double v[SEL_T];
-        for (int u = 0; u < SEL_T; ++u) v[u] = (double)key2f(LEVEL == 1 ? s_prefix[u] << 10 : s_prefix[u]);
+        // level 1 ending the selection: the floats' low 10 bits are zero, i.e. the keys' are 0 (value >= 0,
+        // key top bit set) or all ones (negative values: the key is the complement)
+        for (int u = 0; u < SEL_T; ++u) {
+            uint32_t key = s_prefix[u];
+            if (LEVEL == 1) key = (key << 10) | ((key >> 21) & 1u ? 0u : 1023u);
+            v[u] = (double)key2f(key);
+        }
         if (!(stats5[0] >= v[6])) stats5[0] = v[6];          // also replaces the initial NaN
         stats5[1] = lerp_pair(v[0], v[1], n, 0.05);
         stats5[2] = lerp_pair(v[2], v[3], n, 0.50);
@@ -324,9 +330,9 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, co
                 // instruction per key kind (their issue rate is what the pass costs beyond its loads)
                 if (act && sr >= 0) atomicAdd(&h[sr * NB + dr], 1u);
                 if (act && sl >= 0) atomicAdd(&h[sl * NB + dl], 1u);
-                if (LEVEL == 1) {
-                    low |= (act && sr >= 0) ? (kr & 1023u) : 0u;
-                    low |= (act && sl >= 0) ? (kl & 1023u) : 0u;
+                if (LEVEL == 1) {                          // low 10 bits of the FLOAT (not of the key: negative keys are complemented)
+                    low |= (act && sr >= 0) ? (__float_as_uint(r[u]) & 1023u) : 0u;
+                    low |= (act && sl >= 0) ? (__float_as_uint((float)l[u]) & 1023u) : 0u;
                 }
             }
         }
