@@ -55,7 +55,10 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    # 10 warm-up rollouts: a freshly reset batch has every env in the same episode phase, and the rollout
+    # kernel is ~10 % slower until the episodes have drifted apart (reset draws cluster; trace: 504, 531,
+    # ... 481, 456, 447 us over 31 consecutive rollouts); training runs in the drifted-apart regime
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--env", default="cartpole", choices=["cartpole", "acrobot"])
     p.add_argument("--num-envs", type=int, default=65536, help="envs PER GPU")
     p.add_argument("--rollout-len", type=int, default=128)

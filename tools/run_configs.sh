@@ -1,7 +1,7 @@
 #!/bin/bash
-# One measured line per BASELINE.json config on one MI355X; outputs under gpurun_out/r01/configs/.
+# One measured line per BASELINE.json config on one MI355X; outputs under gpurun_out/<round>/configs/.
 set -o pipefail
-o=gpurun_out/r01/configs
+o=gpurun_out/${PPO_ROUND:-r02}/configs
 mkdir -p $o
 # C1: plumbing run through the CLI, CartPole, 8 envs x 128 steps, 20 updates
 PPO_AMD_METRICS=$o/c1_metrics.jsonl PPO_AMD_SEED=1 timeout -k 10 300 python3 -m ppo_amd.ppo_cli c1 env_cartpole 20 8 128 4 256 0.5 0.01 0.2 0.5 0.00025 0.99 0.95 1 1 0 1 --use_gpu 1 > $o/c1.log 2>&1 || { tail -20 $o/c1.log; exit 1; }
