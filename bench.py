@@ -54,11 +54,13 @@ GAE_BYTES_PER_ELEM = 20        # r, v, done, trunc read + adv written; the end v
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    # 10 warm-up rollouts: a freshly reset batch has every env in the same episode phase, and the rollout
-    # kernel is ~10 % slower until the episodes have drifted apart (reset draws cluster; trace: 504, 531,
-    # ... 481, 456, 447 us over 31 consecutive rollouts); training runs in the drifted-apart regime
-    p.add_argument("--warmup", type=int, default=10)
+    # Defaults: 100 warm-up rollouts, 50 timed.  After an idle period the GPU's clocks take ~40 ms of
+    # sustained work to settle (tools/rollout_phase.py: the VALU-bound rollout kernel runs 508, 550, ...
+    # 481 (30th), 447 (60th), 435 us (80th and on) -- the same curve after a 0.5 s pause with the same env
+    # batch, so it is the clock / power ramp, not the episode phases); a training run lives in the
+    # settled regime, and that is what the default invocation measures.
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=100)
     p.add_argument("--env", default="cartpole", choices=["cartpole", "acrobot"])
     p.add_argument("--num-envs", type=int, default=65536, help="envs PER GPU")
     p.add_argument("--rollout-len", type=int, default=128)
