@@ -66,6 +66,7 @@ def parse():
     p.add_argument("--rollout-len", type=int, default=128)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-train-step", action="store_true")
+    p.add_argument("--train-step-timeout", type=float, default=240.0)
     p.add_argument("--gae-event-every", type=int, default=1,
                    help="time every K-th GAE dispatch of the timed region with a start/stop event pair (0: none)")
     p.add_argument("--cpu-sample-envs", type=int, default=4096)
@@ -343,10 +344,27 @@ def main():
     del ve
     torch.cuda.empty_cache()
     if not args.no_train_step:
+        # The headline line must not be lost to this extra section: an exception is reported inside the
+        # line, and if the section does not finish in time (a rank stuck in a collective because another
+        # one failed), a watchdog prints the line without it and ends the process.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["train_step"] = {"error": f"did not finish within {args.train_step_timeout} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.train_step_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             rates = train_step_rates(kind, N, T, world, args.seed)
-        except Exception as e:       # the headline line must not be lost to the extra section
+        except Exception as e:
             rates = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            torch.distributed.barrier()              # every rank is through before the watchdog is disarmed
+        watchdog.cancel()
         if rank == 0:
             line["train_step"] = rates
     if rank == 0:
