@@ -150,6 +150,13 @@ def sample_uniform(seed, env_base, step, N):
     return u
 
 
+def div_by_total_mass_mismatches(n, seed=0, e_lo=-40, e_hi=20):
+    """How many of n random doubles (exponent in [e_lo, e_hi)) the device's three-FMA x / 1.1 gets wrong."""
+    f = lib().oracle_div_by_total_mass_mismatches
+    f.restype = C.c_long
+    return int(f(C.c_long(n), C.c_uint64(seed), C.c_int(e_lo), C.c_int(e_hi)))
+
+
 def categorical_check(logits, u, actions, margin=1e-5):
     """Inverse-CDF sampling check in float64: returns (mismatches, ambiguous) -- the number of rows whose
     action differs from the first k with u * sum < cdf_k although u * sum is further than `margin`

