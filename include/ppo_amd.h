@@ -318,6 +318,24 @@ int ppo_episode_stats(const float *ret_ring, const int *len_ring, const int *rin
                       int N, double *stats5, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/*
+ * The same statistics (src/ppo.py:404-417), same results bit for bit, for rings that only change by
+ * episodes being appended between calls -- ppo_env_step / ppo_rollout_fused writing slot
+ * ring_cnt % ring and incrementing ring_cnt, i.e. the reference's deque.append.  Only the slots
+ * written since the previous call are visited (a 128-step rollout finishes a handful of episodes
+ * per env, the rings hold 100); the two full passes of ppo_episode_stats run only on the first
+ * call, when a percentile has moved to a different 12-bit key prefix, or for non-integer values.
+ * state: ppo_episode_stats_state_bytes(N, ring) bytes of device memory, 16-byte aligned, ZERO-FILLED
+ * by the caller once; it belongs to ONE set of rings (it holds each env's count and a copy of the
+ * rings as of the last call, 8 * N * ring bytes).  Zero-fill it again whenever the rings were written
+ * by anything else (a restored checkpoint, a count that went down); the next call then starts over
+ * from the full rings.  Calls on one state must not overlap.
+ */
+size_t ppo_episode_stats_state_bytes(int N, int ring);
+int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, const int *ring_cnt,
+                                  int ring, int N, double *stats5, void *state, size_t state_bytes,
+                                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,17 @@
 //              rank (one wave per target, shuffle scans); the last level writes {running max, p5, p50,
 //              p95, median length}.  Three launches; level 2 returns at once when level 1 found the
 //              low 10 bits of every wanted key clear (integer-valued returns and lengths).
+//
+// Incremental form (ppo_episode_stats_incremental): between two calls only the episodes that finished
+// in between change the rings -- ~6 of an env's 100 slots per 128-step CartPole rollout under a random
+// policy, fewer once the policy holds the pole.  A caller-owned state block keeps, across calls, the
+// level-0 histograms, the level-1 histograms of the nine prefixes the wanted ranks were last found
+// under, a count of window entries with low float bits set, each env's ring count at the last call and
+// a shadow copy of the rings (the value an overwritten slot held).  k_sel_incr visits only the slots
+// written since the last call (four lanes per env), subtracts the shadow value, adds the new one and
+// narrows from the persistent histograms; the two full passes above run only when a wanted rank has
+// moved to a prefix that is not tracked (level 1 rebuilds those histograms) or when values are not
+// integers (level 2) -- otherwise they return at once.
 #include "common.h"
 
 namespace {
@@ -40,6 +51,12 @@ struct SelState {                 // lives at the head of the workspace
     uint32_t ticket;              // workgroups of the running pass that have flushed their histogram (0 between passes)
     uint32_t low_bits;            // level 1: nonzero if a value that matched a wanted prefix has low float bits set
     int skip2;                    // set by level 1 when low_bits == 0: every wanted key is already known, level 2 returns at once
+    // incremental form only (zero = nothing tracked yet)
+    int skip1;                    // level 1 returns at once: the tracked histograms already cover every wanted rank
+    int ntrack_ret, ntrack;       // prefixes whose level-1 histograms persist in hist1 (same list layout as lprefix / lslot)
+    uint32_t tprefix[SEL_T];
+    int tslot[SEL_T];
+    long long nz;                 // window entries (returns and lengths) whose float pattern has low 10 bits set
 };
 
 struct SelWs {
@@ -94,13 +111,16 @@ __device__ double lerp_pair(double a, double b, unsigned long long n, double q)
 // registers: the narrowing runs inside the histogram kernel, whose register budget -- two
 // 1024-thread workgroups per CU -- it must not raise; walking them in global memory instead costs a
 // DRAM latency per bin, 100+ us).  The nine targets are narrowed concurrently by nine waves.
-template <int PER> struct WaveBins {
+// STRIDE: words between the bins of consecutive lanes in LDS.  With 64 bins per lane (level 0) a stride
+// of 64 words puts all 64 lanes of a ds_read_b128 on the same banks; the level-0 copy is therefore
+// padded to 68 words per lane (SEL_PAD0).
+template <int PER, int STRIDE = PER> struct WaveBins {
     const uint32_t *bins;
     unsigned long long excl, incl, total;
     __device__ __forceinline__ void load(const uint32_t *b)
     {
         const int lane = threadIdx.x & 63;
-        bins = b + lane * PER;
+        bins = b + lane * STRIDE;
         const uint4 *p = reinterpret_cast<const uint4 *>(bins);
         unsigned long long s = 0;
 #pragma unroll 4
@@ -127,7 +147,7 @@ template <int PER> struct WaveBins {
         const bool here = rank >= excl && rank < incl;
         const int src = __ffsll((long long)__ballot(here)) - 1;
         const unsigned long long base = __shfl(excl, src, 64);            // entries before the owning lane's bins
-        const uint32_t *owner = bins + (src - lane) * PER;                // this lane's `bins` is offset by lane * PER
+        const uint32_t *owner = bins + (src - lane) * STRIDE;             // this lane's `bins` is offset by lane * STRIDE
         const unsigned long long v = lane < PER ? owner[lane] : 0ull;
         unsigned long long inc = v;
 #pragma unroll
@@ -143,13 +163,102 @@ template <int PER> struct WaveBins {
     }
 };
 
+// The finished global histogram into the last workgroup's LDS.  The words were produced by device-scope
+// atomics, so they are read with device-scope atomic loads (a plain load may hit a stale line in this
+// XCD's L2); all of a thread's loads are issued (sel_fetch) before the first is consumed (sel_store) --
+// one round trip, not one per word (a load / LDS-store loop cost ~0.6 us per iteration here).
+// PAD0: the level-0 layout of the copy, 64-word chunks 68 words apart (see WaveBins).
+constexpr int SEL_PAD0 = 68;
+constexpr int SEL_H0_LDS = 2 * (SEL_B0 / 64) * SEL_PAD0;      // words of a padded copy of hist0
+template <int WORDS> struct SelFetch {
+    static_assert(WORDS % 2 == 0, "pairs");
+    static constexpr int PAIRS = WORDS / 2, PER = (PAIRS + SEL_HBLOCK - 1) / SEL_HBLOCK;
+    unsigned long long v[PER];
+    __device__ __forceinline__ void fetch(uint32_t *g)
+    {
+        unsigned long long *g2 = reinterpret_cast<unsigned long long *>(g);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int k = threadIdx.x + i * SEL_HBLOCK;
+            v[i] = k < PAIRS ? __hip_atomic_load(&g2[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+    }
+    template <bool PAD0> __device__ __forceinline__ void store(uint32_t *lds) const
+    {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int k = threadIdx.x + i * SEL_HBLOCK;
+            const int word = PAD0 ? 2 * k + ((2 * k) >> 6) * (SEL_PAD0 - 64) : 2 * k;
+            if (k < PAIRS) *reinterpret_cast<unsigned long long *>(lds + word) = v[i];
+        }
+    }
+};
+
 constexpr int SEL_SWAVES = SEL_T;        // narrowing: one wave per target, the first nine waves of the workgroup
 
+// Hands the next level its work (one thread): targets with equal prefixes share a histogram; the
+// distinct prefixes go into two compact lists (returns from entry 0, lengths from SEL_T_RET).
+// `track`: the incremental form remembers the same lists as the prefixes whose level-1 histograms persist.
+__device__ void sel_setup_next(SelState *st, const uint32_t *prefix, const unsigned long long *rank,
+                               unsigned long long n, bool track)
+{
+    st->n = n;
+    for (int u = 0; u < SEL_T; ++u) {
+        int sl = u;
+        for (int q = (u < SEL_T_RET ? 0 : SEL_T_RET); q < u; ++q)
+            if (prefix[q] == prefix[u]) { sl = q; break; }
+        st->slot[u] = sl;
+        st->leader[u] = sl == u;
+        st->rank[u] = rank[u];
+        st->prefix[u] = prefix[u];
+    }
+    int nr = 0, nl = 0;
+    for (int u = 0; u < SEL_T; ++u) {
+        if (!st->leader[u]) continue;
+        const int at = u < SEL_T_RET ? nr++ : SEL_T_RET + nl++;
+        st->lprefix[at] = prefix[u];
+        st->lslot[at] = u;
+        if (track) { st->tprefix[at] = prefix[u]; st->tslot[at] = u; }
+    }
+    st->nlead_ret = nr;
+    st->nlead = nr + nl;
+    if (track) { st->ntrack_ret = nr; st->ntrack = nr + nl; }
+}
+
+// The nine selected keys -> stats5 = {running max, p5, p50, p95, median length} (one thread).
+// `bits`: key bits known (22 when the floats' low 10 bits are zero, i.e. the keys' are 0 for values >= 0
+// -- key top bit set -- or all ones for negative values, whose key is the complement; else 32).
+__device__ void sel_finalize(double *stats5, const uint32_t *prefix, int bits, unsigned long long n)
+{
+    double v[SEL_T];
+    for (int u = 0; u < SEL_T; ++u) {
+        uint32_t key = prefix[u];
+        if (bits == 22) key = (key << 10) | ((key >> 21) & 1u ? 0u : 1023u);
+        v[u] = (double)key2f(key);
+    }
+    if (!(stats5[0] >= v[6])) stats5[0] = v[6];              // also replaces the initial NaN
+    stats5[1] = lerp_pair(v[0], v[1], n, 0.05);
+    stats5[2] = lerp_pair(v[2], v[3], n, 0.50);
+    stats5[3] = lerp_pair(v[4], v[5], n, 0.95);
+    stats5[4] = lerp_pair(v[7], v[8], n, 0.50);
+}
+
+// rank of target t among n values: (lower, upper) neighbours of p5, p50, p95 of the returns, their
+// maximum, (lower, upper) of the median length
+__device__ unsigned long long sel_target_rank(int t, unsigned long long n)
+{
+    unsigned long long lo, hi;
+    rank_pair(n, t < 2 ? 0.05 : (t < 4 || t >= SEL_T_RET ? 0.50 : 0.95), lo, hi);
+    const bool upper = t < 6 ? (t & 1) : (t == 8);
+    return t == 6 ? n - 1 : (upper ? hi : lo);
+}
+
 // Narrowing of one level, run by the LAST workgroup of that level's histogram pass to finish (every
-// thread of the workgroup calls it).  stats5 = {running max, p5, p50, p95, median length}; entries
-// keep their previous value (NaN at start) while no episode has finished, like the reference's
-// attributes (src/ppo.py:250-254, :408-417).
-template <int LEVEL> __device__ void sel_narrow(const SelWs &w, const uint32_t *hist, double *stats5)
+// thread of the workgroup calls it).  stats5 entries keep their previous value (NaN at start) while
+// no episode has finished, like the reference's attributes (src/ppo.py:250-254, :408-417).
+// INCR (incremental form): hist0 and hist1 persist between calls and are never cleared here, and
+// whether level 2 is needed comes from the state's running count `nz` instead of this pass.
+template <int LEVEL, bool INCR> __device__ void sel_narrow(const SelWs &w, const uint32_t *hist, double *stats5)
 {
     __shared__ unsigned long long s_rank[SEL_T];
     __shared__ uint32_t s_prefix[SEL_T];
@@ -161,14 +270,11 @@ template <int LEVEL> __device__ void sel_narrow(const SelWs &w, const uint32_t *
     uint32_t prefix = 0;
     if (LEVEL == 0) {
         if (worker) {
-            WaveBins<SEL_B0 / 64> wb;
-            wb.load(hist + (t < SEL_T_RET ? 0 : SEL_B0));
+            WaveBins<SEL_B0 / 64, SEL_PAD0> wb;
+            wb.load(hist + (t < SEL_T_RET ? 0 : SEL_H0_LDS / 2));
             n = wb.total;                                        // same for returns and lengths
             if (n > 0) {
-                unsigned long long lo, hi;
-                rank_pair(n, t < 2 ? 0.05 : (t < 4 || t >= SEL_T_RET ? 0.50 : 0.95), lo, hi);
-                const bool upper = t < 6 ? (t & 1) : (t == 8);   // targets come in (lower, upper) pairs
-                rank = t == 6 ? n - 1 : (upper ? hi : lo);
+                rank = sel_target_rank(t, n);
                 prefix = (uint32_t)wb.find(rank);
             }
             if (threadIdx.x == 0) s_n = n;
@@ -193,15 +299,18 @@ template <int LEVEL> __device__ void sel_narrow(const SelWs &w, const uint32_t *
     // Level 1 ends the selection when every value that matched a wanted 12-bit prefix has the low 10
     // bits of its float pattern clear (integer-valued returns and lengths -- CartPole, Acrobot: always):
     // the 22 bits known now determine the whole key, and level 2 returns at once.
-    const bool last = LEVEL == 2 ||
-                      (LEVEL == 1 && __hip_atomic_load(&st->low_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);
+    bool last = LEVEL == 2;
+    if (LEVEL == 1) {
+        last = INCR ? __hip_atomic_load(&st->nz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0
+                    : __hip_atomic_load(&st->low_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    }
     // Histograms are cleared here for the next call as soon as they have been consumed (level 1:
     // hist0, read by level 0's narrowing; the last level: hist1, and hist2 if level 2 filled it), so
     // that a call finds the workspace zeroed and leaves it zeroed without a memset launch.
-    if (LEVEL == 1) {
+    if (LEVEL == 1 && !INCR) {
         for (int k = threadIdx.x; k < 2 * SEL_B0; k += SEL_HBLOCK) w.hist0[k] = 0u;
     }
-    if (LEVEL >= 1 && last) {
+    if (LEVEL >= 1 && last && !INCR) {
         for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_HBLOCK) w.hist1[k] = 0u;
     }
     if (LEVEL == 2) {
@@ -210,56 +319,25 @@ template <int LEVEL> __device__ void sel_narrow(const SelWs &w, const uint32_t *
     if (threadIdx.x != 0) return;
     if (LEVEL == 0) __hip_atomic_store(&st->low_bits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (LEVEL == 1) st->skip2 = last ? 1 : 0;
-    if (!last) {                                             // targets with equal prefixes share a histogram
-        st->n = n;
-        for (int u = 0; u < SEL_T; ++u) {
-            int sl = u;
-            for (int q = (u < SEL_T_RET ? 0 : SEL_T_RET); q < u; ++q)
-                if (s_prefix[q] == s_prefix[u]) { sl = q; break; }
-            st->slot[u] = sl;
-            st->leader[u] = sl == u;
-            st->rank[u] = s_rank[u];
-            st->prefix[u] = s_prefix[u];
-        }
-        int nr = 0, nl = 0;                                  // returns' leaders from entry 0, lengths' from SEL_T_RET
-        for (int u = 0; u < SEL_T; ++u) {
-            if (!st->leader[u]) continue;
-            const int at = u < SEL_T_RET ? nr++ : SEL_T_RET + nl++;
-            st->lprefix[at] = s_prefix[u];
-            st->lslot[at] = u;
-        }
-        st->nlead_ret = nr;
-        st->nlead = nr + nl;
-    } else {
-        double v[SEL_T];
-        // level 1 ending the selection: the floats' low 10 bits are zero, i.e. the keys' are 0 (value >= 0,
-        // key top bit set) or all ones (negative values: the key is the complement)
-        for (int u = 0; u < SEL_T; ++u) {
-            uint32_t key = s_prefix[u];
-            if (LEVEL == 1) key = (key << 10) | ((key >> 21) & 1u ? 0u : 1023u);
-            v[u] = (double)key2f(key);
-        }
-        if (!(stats5[0] >= v[6])) stats5[0] = v[6];          // also replaces the initial NaN
-        stats5[1] = lerp_pair(v[0], v[1], n, 0.05);
-        stats5[2] = lerp_pair(v[2], v[3], n, 0.50);
-        stats5[3] = lerp_pair(v[4], v[5], n, 0.95);
-        stats5[4] = lerp_pair(v[7], v[8], n, 0.50);
-    }
+    if (LEVEL == 1 && INCR) st->skip1 = 1;                   // the tracked histograms are complete again
+    if (!last) sel_setup_next(st, s_prefix, s_rank, n, false);
+    else sel_finalize(stats5, s_prefix, LEVEL == 1 ? 22 : 32, n);
 }
 
-template <int LEVEL>
+template <int LEVEL, bool INCR>
 __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, const int *len_ring, const int *ring_cnt,
                                                       int ring, int N, SelWs w, double *stats5)
 {
     constexpr int NH = LEVEL == 0 ? 2 : SEL_T, NB = LEVEL == 0 ? SEL_B0 : SEL_B1;
     constexpr int SHIFT = LEVEL == 0 ? 20 : (LEVEL == 1 ? 10 : 0);     // digit position
     constexpr int PSHIFT = LEVEL == 1 ? 20 : 10;                       // bits below the fixed prefix
-    __shared__ uint32_t h[NH * NB];
+    __shared__ uint32_t h[LEVEL == 0 ? SEL_H0_LDS : NH * NB];   // level 0: room for the padded copy the narrowing reads
     __shared__ int s_is_last;
     uint32_t lprefix[SEL_T];
     int lslot[SEL_T], nlead_ret = 0, nlead = 0;
     if (LEVEL > 0) {
         if (w.st->n == 0) return;                                      // uniform: nothing finished yet
+        if (INCR && LEVEL == 1 && w.st->skip1) return;                 // uniform: every wanted prefix is tracked
         if (LEVEL == 2 && w.st->skip2) return;                         // uniform: level 1 finished the selection
         nlead_ret = __builtin_amdgcn_readfirstlane(w.st->nlead_ret);
         nlead = __builtin_amdgcn_readfirstlane(w.st->nlead);
@@ -337,7 +415,7 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, co
             }
         }
     }
-    if (LEVEL == 1) {
+    if (LEVEL == 1 && !INCR) {
         if (__any(low != 0u) && lane == 0) atomicOr(&w.st->low_bits, 1u);   // device-scope atomic, like the histogram adds
     }
     __syncthreads();
@@ -359,18 +437,256 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, co
     __syncthreads();
     if (!s_is_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(&w.st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next pass
-    for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK)  // the finished histogram into this workgroup's LDS
-        h[k] = __hip_atomic_load(&g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SelFetch<NH * NB> f;                                     // the finished histogram into this workgroup's LDS
+    f.fetch(g);
+    __syncthreads();                                         // (level 0: every thread is done with the unpadded layout)
+    f.template store<LEVEL == 0>(h);
     __syncthreads();
-    sel_narrow<LEVEL>(w, h, stats5);
+    sel_narrow<LEVEL, INCR>(w, h, stats5);
 }
 
-template <int LEVEL>
+template <int LEVEL, bool INCR = false>
 int sel_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N, const SelWs &w,
               double *stats5, unsigned blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sel<LEVEL>, dim3(blocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5);
+    hipLaunchKernelGGL((k_sel<LEVEL, INCR>), dim3(blocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5);
     return ppo_launch_status();
+}
+
+// ---- incremental form -------------------------------------------------------------------------
+constexpr size_t INCR_HEAD_BYTES = (SEL_WS_BYTES + 255) / 256 * 256;
+
+struct IncrBufs {                        // behind the histograms in the state block
+    int *cnt_prev;                       // [N]        ring_cnt at the last call
+    uint2 *shadow;                       // [N, ring]  the rings as they were at the last call: {return bits, length}
+};
+
+inline size_t incr_cnt_bytes(int N) { return ((size_t)N * sizeof(int) + 255) / 256 * 256; }
+inline size_t incr_state_bytes(int N, int ring)
+{
+    return INCR_HEAD_BYTES + incr_cnt_bytes(N) + 2 * (size_t)N * (size_t)ring * sizeof(float);
+}
+
+// One value entering (sign = +1) or leaving (-1) the window: level-0 bin, the level-1 bin of a
+// tracked prefix, and the count of values that need level 2.  The deltas are two's-complement adds
+// into LDS words that start at zero.
+__device__ __forceinline__ void incr_apply(uint32_t *h0, uint32_t *h1, uint32_t sign, float r, int l,
+                                           const uint32_t (&tprefix)[SEL_T], const int (&tslot)[SEL_T],
+                                           int ntrack_ret, int ntrack, int &nz)
+{
+    const float lf = (float)l;
+    const uint32_t kr = f2key(r), kl = f2key(lf);
+    atomicAdd(&h0[kr >> 20], sign);
+    atomicAdd(&h0[SEL_B0 + (kl >> 20)], sign);
+    const uint32_t pr = kr >> 20, pl = kl >> 20;
+    int sr = -1, sl = -1;
+#pragma unroll
+    for (int q = 0; q < SEL_T_RET; ++q) {
+        if (q < ntrack_ret && pr == tprefix[q]) sr = tslot[q];
+    }
+#pragma unroll
+    for (int q = 0; q < SEL_T - SEL_T_RET; ++q) {
+        if (q < ntrack - ntrack_ret && pl == tprefix[SEL_T_RET + q]) sl = tslot[SEL_T_RET + q];
+    }
+    if (sr >= 0) atomicAdd(&h1[sr * SEL_B1 + ((kr >> 10) & (SEL_B1 - 1))], sign);
+    if (sl >= 0) atomicAdd(&h1[sl * SEL_B1 + ((kl >> 10) & (SEL_B1 - 1))], sign);
+    nz += (int)sign * (((__float_as_uint(r) & 1023u) != 0u) + ((__float_as_uint(lf) & 1023u) != 0u));
+}
+
+constexpr int INCR_ENVS = 256;           // envs a workgroup takes per pass (their new slots are shared out over all 1024 threads)
+
+__global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr(const float *__restrict__ ret_ring, const int *__restrict__ len_ring,
+                                                           const int *__restrict__ ring_cnt, int ring, int N, SelWs w,
+                                                           IncrBufs ib, double *stats5)
+{
+    __shared__ uint32_t h0[SEL_H0_LDS];                        // deltas in the first 2 * SEL_B0 words; later the padded copy
+    __shared__ uint32_t h1[SEL_T * SEL_B1];
+    __shared__ int s_is_last;
+    __shared__ unsigned long long s_rank[SEL_T];
+    __shared__ uint32_t s_prefix[SEL_T];
+    __shared__ int s_row[SEL_T];
+    __shared__ unsigned long long s_n;
+    __shared__ uint32_t s_first[INCR_ENVS + 1];               // work items before env e of this pass (exclusive prefix of m)
+    __shared__ int s_c0[INCR_ENVS], s_c1[INCR_ENVS];
+    __shared__ uint32_t s_wsum[INCR_ENVS / 64];
+    SelState *st = w.st;
+    uint2 *__restrict__ shadow = ib.shadow;
+    uint32_t tprefix[SEL_T];
+    int tslot[SEL_T];
+    const int ntrack_ret = __builtin_amdgcn_readfirstlane(st->ntrack_ret);
+    const int ntrack = __builtin_amdgcn_readfirstlane(st->ntrack);
+#pragma unroll
+    for (int q = 0; q < SEL_T; ++q) {
+        tprefix[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)st->tprefix[q]);
+        tslot[q] = __builtin_amdgcn_readfirstlane(st->tslot[q]);
+    }
+    for (int k = threadIdx.x; k < 2 * SEL_B0; k += SEL_HBLOCK) h0[k] = 0u;
+    for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_HBLOCK) h1[k] = 0u;
+
+    // Slots written since the last call: entries i in [c1 - m, c1) of env n's ring, m = min(c1 - c0, ring),
+    // at slot i % ring; what such a slot held before (the shadow copy) was in the old window iff the ring
+    // had wrapped (c0 >= ring) or the slot was filled (slot < c0).  A pass takes 256 envs: their counts
+    // are read coalesced, a prefix sum over m numbers the (env, entry) pairs, and the 1024 threads take
+    // pairs round robin -- two at a time, all eight loads in flight before the first is used: the
+    // accesses are scattered 4-byte reads, latency is what they cost.
+    const uint32_t uring = (uint32_t)ring;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int nz = 0;
+    for (int env0 = blockIdx.x * INCR_ENVS; env0 < N; env0 += gridDim.x * INCR_ENVS) {
+        __syncthreads();                                       // LDS clears done / the previous pass has read s_first
+        uint32_t m = 0, incl = 0;
+        int c0 = 0, c1 = 0;
+        if (threadIdx.x < INCR_ENVS) {
+            const int n = env0 + threadIdx.x;
+            if (n < N) {
+                c1 = max(ring_cnt[n], 0);
+                c0 = ib.cnt_prev[n];
+                m = (uint32_t)max(min(c1 - c0, ring), 0);      // a count that went DOWN is not supported: treated as unchanged
+                if (m > 0) ib.cnt_prev[n] = c1;
+            }
+            incl = m;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) s_wsum[wv] = incl;
+            s_c0[threadIdx.x] = c0;
+            s_c1[threadIdx.x] = c1;
+        }
+        __syncthreads();
+        if (threadIdx.x < INCR_ENVS) {
+            uint32_t before = 0;
+            for (int q = 0; q < wv; ++q) before += s_wsum[q];
+            s_first[threadIdx.x] = before + incl - m;
+            if (threadIdx.x == INCR_ENVS - 1) s_first[INCR_ENVS] = before + incl;
+        }
+        __syncthreads();
+        const uint32_t items = s_first[INCR_ENVS];
+        for (uint32_t it0 = threadIdx.x; it0 < items; it0 += 2 * SEL_HBLOCK) {
+            size_t at[2];
+            bool live[2], old_valid[2];
+            float r_new[2], r_old[2];
+            int l_new[2], l_old[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t it = it0 + u * SEL_HBLOCK;
+                live[u] = it < items;
+                int e = 0;                                     // largest e with s_first[e] <= it
+#pragma unroll
+                for (int stepb = INCR_ENVS / 2; stepb > 0; stepb >>= 1)
+                    if (s_first[e + stepb] <= it) e += stepb;
+                if (!live[u]) e = 0;
+                const uint32_t first = s_first[e], cnt_e = s_first[e + 1] - first;
+                const int ec0 = s_c0[e], ec1 = s_c1[e];
+                const uint32_t i = (uint32_t)ec1 - cnt_e + (it - first);
+                const uint32_t slot = live[u] ? i % uring : 0u;
+                at[u] = (size_t)(env0 + e) * uring + slot;
+                old_valid[u] = live[u] && (ec0 >= ring || slot < (uint32_t)ec0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                r_new[u] = ret_ring[at[u]]; l_new[u] = len_ring[at[u]];
+                const uint2 old = shadow[at[u]];
+                r_old[u] = __uint_as_float(old.x); l_old[u] = (int)old.y;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (live[u]) {
+                    shadow[at[u]] = make_uint2(__float_as_uint(r_new[u]), (uint32_t)l_new[u]);
+                    incr_apply(h0, h1, 1u, r_new[u], l_new[u], tprefix, tslot, ntrack_ret, ntrack, nz);
+                }
+                if (old_valid[u]) incr_apply(h0, h1, 0xFFFFFFFFu, r_old[u], l_old[u], tprefix, tslot, ntrack_ret, ntrack, nz);
+            }
+        }
+    }
+    nz = (int)wave_sum((double)nz);
+    if ((threadIdx.x & 63) == 0 && nz != 0)
+        __hip_atomic_fetch_add(&st->nz, (long long)nz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * SEL_B0; k += SEL_HBLOCK) {
+        const uint32_t v = h0[k];
+        if (v) atomicAdd(&w.hist0[k], v);
+    }
+    for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_HBLOCK) {
+        const uint32_t v = h1[k];
+        if (v) atomicAdd(&w.hist1[k], v);
+    }
+    // last workgroup to flush narrows (see k_sel for why atomics + vmcnt(0) and no fence)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_is_last = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_is_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SelFetch<2 * SEL_B0> f0;
+    SelFetch<SEL_T * SEL_B1> f1;
+    f0.fetch(w.hist0);
+    f1.fetch(w.hist1);
+    const long long nz_now = threadIdx.x == 0 ? __hip_atomic_load(&st->nz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();                                         // every thread is done with the unpadded h0
+    f0.template store<true>(h0);
+    f1.template store<false>(h1);
+    __syncthreads();
+
+    const int t = wv;
+    const bool worker = t < SEL_SWAVES;
+    unsigned long long n = 0, rank = 0;
+    uint32_t prefix = 0;
+    int row = -1;
+    if (worker) {                                              // level 0 from the persistent histogram
+        WaveBins<SEL_B0 / 64, SEL_PAD0> wb;
+        wb.load(h0 + (t < SEL_T_RET ? 0 : SEL_H0_LDS / 2));
+        n = wb.total;
+        if (n > 0) {
+            rank = sel_target_rank(t, n);
+            prefix = (uint32_t)wb.find(rank);
+            const int q0 = t < SEL_T_RET ? 0 : SEL_T_RET, q1 = t < SEL_T_RET ? ntrack_ret : SEL_T_RET + (ntrack - ntrack_ret);
+            for (int q = q0; q < q1; ++q)
+                if (tprefix[q] == prefix) row = tslot[q];
+        }
+        if (lane == 0) { s_rank[t] = rank; s_prefix[t] = prefix; s_row[t] = row; }
+        if (threadIdx.x == 0) s_n = n;
+    }
+    __syncthreads();
+    n = s_n;
+    if (n == 0) {                                              // nothing finished yet: both full passes return at once
+        if (threadIdx.x == 0) { st->n = 0; st->skip1 = 1; st->skip2 = 1; }
+        return;
+    }
+    bool tracked = true;
+    for (int u = 0; u < SEL_T; ++u) tracked = tracked && s_row[u] >= 0;
+    if (!tracked) {
+        // A wanted rank sits under a prefix without a persistent level-1 histogram: track the nine current
+        // prefixes instead and let the level-1 pass rebuild their histograms from the rings.
+        for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_HBLOCK)
+            __hip_atomic_store(&w.hist1[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            sel_setup_next(st, s_prefix, s_rank, n, true);
+            st->skip1 = 0;
+            st->skip2 = 0;                                     // decided by the level-1 pass
+        }
+        return;
+    }
+    if (worker) {                                              // level 1 from the tracked histograms
+        WaveBins<SEL_B1 / 64> wb;
+        wb.load(h1 + row * SEL_B1);
+        prefix = (prefix << 10) | (uint32_t)wb.find(rank);
+    }
+    __syncthreads();                                           // every wave has read s_rank / s_prefix of level 0
+    if (worker && lane == 0) { s_rank[t] = rank; s_prefix[t] = prefix; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    st->skip1 = 1;
+    if (nz_now == 0) {
+        st->n = n;
+        st->skip2 = 1;
+        sel_finalize(stats5, s_prefix, 22, n);
+    } else {                                                   // values with low float bits set: level 2 over the rings
+        sel_setup_next(st, s_prefix, s_rank, n, false);
+        st->skip2 = 0;
+    }
 }
 
 }  // namespace
@@ -397,6 +713,44 @@ int ppo_episode_stats(const float *ret_ring, const int *len_ring, const int *rin
     rc = sel_level<1>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
     if (rc) return rc;
     return sel_level<2>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
+}
+
+size_t ppo_episode_stats_state_bytes(int N, int ring)
+{
+    if (N < 0 || ring <= 0) return 0;
+    return incr_state_bytes(N, ring);
+}
+
+int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
+                                  double *stats5, void *state, size_t state_bytes, void *stream)
+{
+    PPO_REQUIRE(N >= 0 && ring > 0 && (unsigned long long)N * (unsigned long long)ring < 0xFFFFFFFFull);
+    PPO_REQUIRE(stats5 && ppo_aligned(stats5, 8));
+    PPO_REQUIRE(state && state_bytes >= incr_state_bytes(N, ring) && ppo_aligned(state, 16));
+    if (N == 0) return 0;
+    PPO_REQUIRE(ret_ring && len_ring && ring_cnt);
+    hipStream_t s = (hipStream_t)stream;
+    const SelWs w = sel_ws(state);
+    char *p = static_cast<char *>(state) + INCR_HEAD_BYTES;
+    IncrBufs ib;
+    ib.cnt_prev = reinterpret_cast<int *>(p);
+    ib.shadow = reinterpret_cast<uint2 *>(p + incr_cnt_bytes(N));
+    size_t iblocks = ((size_t)N + INCR_ENVS - 1) / INCR_ENVS;
+    if (iblocks > 256) iblocks = 256;
+    hipLaunchKernelGGL(k_sel_incr, dim3((unsigned)iblocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w,
+                       ib, stats5);
+    int rc = ppo_launch_status();
+    if (rc) return rc;
+    // the two full passes: return at once unless a wanted prefix is untracked (level 1) or values are
+    // not integers (level 2)
+    // (one workgroup per CU instead of two: what these launches cost when they have nothing to do is
+    // the dispatch of their waves)
+    size_t blocks = ((size_t)N * ring + SEL_HBLOCK * SEL_U - 1) / (SEL_HBLOCK * SEL_U);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    rc = sel_level<1, true>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
+    if (rc) return rc;
+    return sel_level<2, true>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
 }
 
 }  // extern "C"

@@ -191,6 +191,7 @@ class SyncVecEnv:
         self._stats_dev = None
         self._stats_pending = False
         self._stats5 = None
+        self._stats_state = None
         self._rsum_pool, self._rsum_next = torch.empty(0), 0
         self._total_return = np.float32(0.0)
         self._end_states = None
@@ -425,22 +426,39 @@ class SyncVecEnv:
     def _flush_stats(self):
         if self._stats_pending:
             self._stats_pending = False
-            self._device_episode_stats()
+            self._device_episode_stats(incremental=True)
 
-    def _device_episode_stats(self):
+    def _device_episode_stats(self, incremental: bool = False):
         """reference src/ppo.py:407-417 on the device rings, without a host round trip: running max,
         5/50/95 percentiles (np.percentile 'linear') of the last <=100 returns of every env, median
-        length -- one ppo_episode_stats call (radix select, ~7 small launches on the rollout's stream).
+        length -- a radix select, three launches on the rollout's stream.  `incremental` (what a rollout
+        uses): ppo_episode_stats_incremental, which visits only the ring slots written since its last
+        call and needs the rings to have changed by appended episodes only (the env kernels);
+        otherwise ppo_episode_stats, a full scan of whatever the rings hold.  Same results.
         The result stays a device tensor until one of the statistics attributes is read."""
         b = self.batch
         lib = ops._lib.load()
         if self._stats5 is None:
             self._stats5 = torch.full((5,), float("nan"), dtype=torch.float64, device=b.device)
             self._stats_ws = torch.zeros(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device=b.device)
-        ops._lib.check(lib.ppo_episode_stats(b.ret_ring.data_ptr(), b.len_ring.data_ptr(), b.ring_cnt.data_ptr(),
-                                             b.ring, b.num_envs, self._stats5.data_ptr(), self._stats_ws.data_ptr(),
-                                             self._stats_ws.numel(), ops._stream()), "ppo_episode_stats")
+        rings = (b.ret_ring.data_ptr(), b.len_ring.data_ptr(), b.ring_cnt.data_ptr(), b.ring, b.num_envs)
+        if incremental:
+            if self._stats_state is None:
+                self._stats_state = torch.zeros(lib.ppo_episode_stats_state_bytes(b.num_envs, b.ring), dtype=torch.uint8,
+                                                device=b.device)
+            ops._lib.check(lib.ppo_episode_stats_incremental(*rings, self._stats5.data_ptr(), self._stats_state.data_ptr(),
+                                                             self._stats_state.numel(), ops._stream()),
+                           "ppo_episode_stats_incremental")
+        else:
+            ops._lib.check(lib.ppo_episode_stats(*rings, self._stats5.data_ptr(), self._stats_ws.data_ptr(),
+                                                 self._stats_ws.numel(), ops._stream()), "ppo_episode_stats")
         self._stats_dev = self._stats5
+
+    def invalidate_episode_stats_state(self):
+        """The rings were written by something other than the env kernels (a restored checkpoint, a test):
+        the next incremental statistics call starts over from the full rings."""
+        if self._stats_state is not None:
+            self._stats_state.zero_()
 
     def _stat(self, key):
         self._flush_stats()
@@ -489,6 +507,7 @@ class SyncVecEnv:
                 raise ValueError(f"checkpoint env batch has {k}={sd[k]}, this run has {getattr(b, k)}")
         for name in _BATCH_TENSORS:
             getattr(b, name).copy_(sd[name])
+        self.invalidate_episode_stats_state()
         b.seed, b.env_base = int(sd["seed"]), int(sd["env_base"])
         self.t_states = sd["t_states"].to(self.device)
         self._rollouts, self.global_steps = int(sd["rollouts"]), int(sd["global_steps"])
