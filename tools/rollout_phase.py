@@ -13,7 +13,7 @@ torch.manual_seed(0)
 agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
 for phase in range(2):
     ve = SyncVecEnv(lambda: DeviceEnv(kind), N, T, 0, 0.0, agent, seed=phase)
-    ve._device_episode_stats = lambda: None
+    ve._device_episode_stats = lambda **kw: None
     ev = []
     for _ in range(K):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -4,6 +4,8 @@ uses wall time over several rollouts with the stats disabled)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from ppo_amd import _lib
+if os.environ.get('PPO_AB_LIB'): _lib.LIB_PATH = os.environ['PPO_AB_LIB']   # A/B runs against another build of the library
 from ppo_amd import Agent, SyncVecEnv, ops
 from ppo_amd.envs import DeviceEnv
 kind = sys.argv[1] if len(sys.argv) > 1 else "cartpole"
@@ -13,7 +15,7 @@ T = 128
 probe = DeviceEnv(kind)
 agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
 ve = SyncVecEnv(lambda: DeviceEnv(kind), N, T, 0, 0.0, agent, seed=0)
-ve._device_episode_stats = lambda: None
+ve._device_episode_stats = lambda **kw: None
 ve.wave_envs = int(os.environ.get('PPO_WAVE_ENVS', '0'))   # 32 / 64: forced
 if os.environ.get('PPO_SPREAD_ELAPSED'):   # TimeLimit counters spread over [0, 500): the steady state of long episodes
     ve.batch.elapsed.copy_(torch.randint(0, 500, (N,), device='cuda', dtype=torch.int32))
