@@ -57,6 +57,15 @@ class DeviceEnvBatch:
         self.ret_ring = torch.zeros((N, ring), dtype=torch.float32, device=dev)
         self.len_ring = torch.zeros((N, ring), dtype=torch.int32, device=dev)
         self.ring_cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._ptrs = None
+
+    def pointers(self):
+        """Device addresses of (state, elapsed, ep_ret, ep_len, episode, ret_ring, len_ring, ring_cnt); the
+        tensors are allocated once and only ever written in place."""
+        if self._ptrs is None:
+            self._ptrs = tuple(t.data_ptr() for t in (self.state, self.elapsed, self.ep_ret, self.ep_len, self.episode,
+                                                      self.ret_ring, self.len_ring, self.ring_cnt))
+        return self._ptrs
 
     def reset(self, obs_out: torch.Tensor | None = None, reset_draw: torch.Tensor | None = None) -> torch.Tensor:
         N = self.num_envs

@@ -7,6 +7,7 @@ with no HIP device every op raises.
 """
 from __future__ import annotations
 
+import functools
 import os
 
 import torch
@@ -332,8 +333,13 @@ def split_ok(diag) -> bool:
 _KIND_OF_OBS = {4: 0, 6: 1}
 
 
+@functools.lru_cache(maxsize=None)
+def _rollout_param_floats(kind: int, joint: int, net_mode: int) -> int:
+    return int(_lib.load().ppo_rollout_param_floats(kind, joint, net_mode))
+
+
 def rollout_param_floats(kind: int, joint, net_mode: int) -> int:
-    return int(_lib.load().ppo_rollout_param_floats(int(kind), int(bool(joint)), int(net_mode)))
+    return _rollout_param_floats(int(kind), int(bool(joint)), int(net_mode))
 
 
 def pack_dense_agent(agent, net_mode: int = NET_F32, out: torch.Tensor | None = None,
@@ -388,14 +394,14 @@ def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, l
     """ppo_rollout_fused over a ppo_amd.envs.DeviceEnvBatch; every tensor is written in place.
     wave_envs != 0 (tests / tuning) forces 32 or 64 envs per wave through the private _ex entry."""
     lib = _lib.load()
-    need = lib.ppo_rollout_param_floats(batch.kind, int(bool(joint)), int(net_mode))
+    need = rollout_param_floats(batch.kind, int(bool(joint)), int(net_mode))
     assert params.numel() == need and params.dtype == torch.float32 and params.is_cuda, (params.numel(), need)
+    bp = batch.pointers()       # (state, elapsed, ep_ret, ep_len, episode, ret_ring, len_ring, ring_cnt): fixed for the batch's life
     args = (
-        batch.kind, batch.state.data_ptr(), batch.elapsed.data_ptr(), batch.ep_ret.data_ptr(),
-        batch.ep_len.data_ptr(), batch.episode.data_ptr(), None, batch.seed, batch.env_base, params.data_ptr(),
+        batch.kind, bp[0], bp[1], bp[2], bp[3], bp[4], None, batch.seed, batch.env_base, params.data_ptr(),
         int(bool(joint)), int(net_mode), int(sample_step0), obs_io.data_ptr(), states.data_ptr(), actions.data_ptr(),
         log_probs.data_ptr(), values.data_ptr(), rewards.data_ptr(), done.data_ptr(), trunc.data_ptr(),
-        term_obs.data_ptr(), _ptr(ev_dense), _ptr(reward_sum), batch.ret_ring.data_ptr(), batch.len_ring.data_ptr(), batch.ring_cnt.data_ptr(),
+        term_obs.data_ptr(), _ptr(ev_dense), _ptr(reward_sum), bp[5], bp[6], bp[7],
         batch.ring, batch.num_envs, int(T))
     if wave_envs:
         rc = lib.ppo_rollout_fused_ex(*args, int(wave_envs), _stream())

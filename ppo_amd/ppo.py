@@ -213,6 +213,8 @@ class SyncVecEnv:
         self._pack = None            # parameters packed for the rollout kernel, see _net()
         self.wave_envs = 0           # tests / tuning: force 32 or 64 envs per wave (0 = the library chooses by N)
         self._rollouts = 0
+        self._bufsets = [None, None]  # see _alloc
+        self._params = None           # list(agent.parameters()), see prepack
 
         first = env_fn()
         self.native = isinstance(first, ppo_envs.DeviceEnv)
@@ -275,8 +277,19 @@ class SyncVecEnv:
                 torch.from_numpy(dones).to(dev), torch.from_numpy(truncs).to(dev))
 
     # -- rollout --------------------------------------------------------------------------
-    def _alloc(self, dev):
+    def _alloc(self, dev, pingpong: bool = False):
+        """The rollout buffers (reference src/ppo.py:306-314 allocates them anew every rollout).
+        pingpong (device rollouts): two sets used alternately instead of seven allocations per rollout
+        -- ~20 us of host time in front of the rollout launch, which is inside the reference's
+        env_steps_per_sec bracket; a reference to a buffer stays valid until the rollout after next."""
         T, N = self.steps_per_env, self.num_envs
+        if pingpong:
+            key = (T, N, str(dev))
+            slot = self._bufsets[self._rollouts & 1]
+            if slot is not None and slot[0] == key:
+                (self.states, self.actions, self.rewards, self.done_flags, self.trunc_flags, self.values,
+                 self.log_probs) = slot[1]
+                return
         self.states = torch.empty((T, N, *self.state_space.shape), dtype=torch.float32, device=dev)
         self.actions = torch.empty((T, N, *self.action_space.shape), dtype=self.action_dtype, device=dev)
         self.rewards = torch.empty((T, N), dtype=torch.float32, device=dev)
@@ -284,6 +297,9 @@ class SyncVecEnv:
         self.trunc_flags = torch.empty((T, N), dtype=torch.int32, device=dev)
         self.values = torch.empty((T, N), dtype=torch.float32, device=dev)
         self.log_probs = torch.empty((T, N), dtype=torch.float32, device=dev)
+        if pingpong:
+            self._bufsets[self._rollouts & 1] = (key, (self.states, self.actions, self.rewards, self.done_flags,
+                                                       self.trunc_flags, self.values, self.log_probs))
 
     def rollout(self):
         """reference src/ppo.py:304-417"""
@@ -300,7 +316,7 @@ class SyncVecEnv:
         self._flush_stats()                            # statistics of the previous rollout, before the rings change
         kdev, adev = self.kdev, torch.device(self.device)
         same = adev.type == "cuda"
-        self._alloc(kdev)
+        self._alloc(kdev, pingpong=same)
         if self._term_obs is None or self._term_obs.shape[0] != T:
             self._term_obs = torch.empty((T, N, b.obs_dim), dtype=torch.float32, device=kdev)
         fused = self.fused_sampling and same and self.agent.discrete
@@ -364,7 +380,9 @@ class SyncVecEnv:
         host synchronisation.  PPO.train_step calls this right behind the last optimizer.step() of an
         update, so that the next rollout starts with its parameters packed.  Returns the device f32[3]
         split_diag still to be read (ops.NET_AUTO), else None."""
-        key = (self.net_mode,) + tuple((id(p), p._version) for p in self.agent.parameters())
+        if self._params is None:                           # walking the module tree costs ~10 us per call
+            self._params = list(self.agent.parameters())
+        key = (self.net_mode,) + tuple([p._version for p in self._params])
         pk = self._pack
         if pk is not None and pk["key"] == key:
             return pk["diag"] if pk["ok"] is None else None
