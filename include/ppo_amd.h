@@ -336,6 +336,40 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
                                   int ring, int N, double *stats5, void *state, size_t state_bytes,
                                   void *stream);
 
+/*
+ * One minibatch of the update for the dense Agent with a Discrete head, fused: forward, loss,
+ * backward and weight gradients in one pass over the samples.  Replaces, for one backbone and the
+ * head(s) on it, Agent.get_actions_and_values on the minibatch (src/ppo.py:166-216, network
+ * :124-145), the ratio (:595), compute_losses (:490-527), the loss assembly (:602-604 joint;
+ * :611-612, :619-620 split networks) and loss.backward() (:606, :614, :622): `grads` receives
+ *   d [ c_pi * policy_loss + c_v * value_loss - c_ent * entropy ] / d parameters
+ * in the order w1 [64, obs], b1 [64], w2 [64, 64], b2 [64], then policy_w [A, 64], policy_b [A] if
+ * heads & 1, then critic_w [64], critic_b [1] if heads & 2 (ppo_dense_update_grad_floats floats;
+ * nn.Linear layouts), and out5 = {policy_loss, value_loss, clip_frac, kl_div, entropy} as
+ * ppo_loss_logits_fwd_bwd defines them (entries of a head that is not given are left untouched).
+ *   heads = 3: joint network.  Split networks: one call with the policy backbone and heads = 1
+ *   (policy_loss, entropy, clip_frac, kl_div), one with the value backbone and heads = 2.
+ *   w1 .. critic_b: the nn.Linear tensors (row-major [out, in]); policy_* / critic_* may be NULL
+ *   for a head that is not given.  states [B, obs] f32, actions [B] i32, old_lp / old_v / adv [B] f32
+ *   (the gathered minibatch); stats3 as for ppo_loss_fwd_bwd.  obs_dim 4 or 6, num_actions 2 or 3.
+ * Arithmetic: exact f32 products (f32 MFMA), tanh = 1 - 2 / (exp(2x) + 1) on the exp2 / rcp units
+ * (absolute error < 2e-7), per-sample loss terms as in ppo_loss_logits_fwd_bwd, gradient sums per
+ * wave in f32 and across waves in f64 in a fixed order (run-to-run deterministic).  Agrees with
+ * PyTorch autograd of the same f32 network to f32 summation-order accuracy.
+ * workspace: ppo_dense_update_workspace_bytes() bytes, 8-byte aligned; not shared between calls
+ * that may overlap.
+ */
+size_t ppo_dense_update_workspace_bytes(void);
+size_t ppo_dense_update_grad_floats(int obs_dim, int num_actions, int heads);
+int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float *w1, const float *b1,
+                           const float *w2, const float *b2, const float *policy_w,
+                           const float *policy_b, const float *critic_w, const float *critic_b,
+                           const float *states, const int *actions, const float *old_lp,
+                           const float *old_v, const float *adv, const double *stats3, double clip,
+                           int norm_adv, int clip_va, long B, double c_pi, double c_v, double c_ent,
+                           float *out5, float *grads, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,542 @@
+// Fused PPO minibatch update of the dense Agent with a Discrete head -- gfx950.
+//
+// What it replaces: one iteration of the reference's minibatch loop between the gathers and the
+// optimiser (src/ppo.py:589-625): Agent.get_actions_and_values on the minibatch (:166-216, network
+// :124-145: Linear(obs, 64)-tanh-Linear(64, 64)-tanh, policy head, critic head), the probability
+// ratio (:595), compute_losses (:490-527), the loss assembly (:602-604 / :611-612, :619-620) and
+// loss.backward().  PyTorch runs that as ~40 kernels over [B, 64] activation tensors (B = 2 M at
+// BASELINE configs[1] with four minibatches: 3.7 ms, bound by activation traffic); here a sample's
+// activations never leave the CU: forward, loss derivative, backward and the weight-gradient
+// accumulation happen in one pass that reads ~40 B per sample.
+//
+// One wave works on 32 samples at a time (grid-stride).  All matrix products are exact-f32 MFMAs
+// (v_mfma_f32_32x32x2_f32); a 32 x 32 result tile has lane = column, register r = row
+// (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+//   forward    h1 = tanh(W1 x + b1), h2 = tanh(W2 h1 + b2): weights are the A operand (fragments in
+//              LDS, built by the workgroup from the nn.Linear tensors when it starts), the 32 samples
+//              are the columns, and a result register is the next layer's B operand as it is
+//              (k order chosen to match, as in rollout.hip).  Heads: per-lane partial dot products
+//              over the 32 units a lane holds, completed across the two lane halves.
+//   loss       per sample (both lane halves redundantly): Categorical front end + clipped surrogate
+//              / value / entropy terms and their derivatives (loss_core.h, shared with loss.hip).
+//   backward   dz2 = (Whead^T dout) (1 - h2^2) on the VALU; dh1 = W2^T dz2 again register-chained
+//              (transposed fragments in LDS); dz1 = dh1 (1 - h1^2).
+//   gradients  dW2 = sum_s dz2 h1^T etc. need the SAMPLES as the MFMA k dimension, i.e. operands with
+//              lane = unit: the wave transposes dz2 / h1 / dz1 / h2 through its own LDS staging tiles
+//              ([unit][sample], padded) and accumulates the 32 x 32 gradient tiles over all of its
+//              samples in MFMA accumulators; bias gradients are column sums kept per lane.
+// Every wave then writes its partial gradients in the parameters' own layout; k_update_reduce adds
+// the waves' partials in index order in f64 (deterministic) and finishes the loss scalars.
+#include "common.h"
+#include "loss_core.h"
+#include "net_layout.h"
+
+using namespace ppo_net;
+using namespace ppo_loss;
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+#define UPD_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
+
+constexpr int UPD_BLOCK = 256;            // 4 waves, one per SIMD
+constexpr int UPD_MAX_BLOCKS = 256;       // one workgroup per CU (LDS: ~110 KB)
+constexpr int SPAD = 33;                  // staging row: 32 samples + 1 (conflict-free transposed reads)
+constexpr int NSCAL = 5;                  // sum m, sum vterm, sum clipped, sum kl, sum H
+
+struct Net {                              // one backbone + the heads that hang on it (nn.Linear layouts)
+    const float *w1, *b1, *w2, *b2;       // [64, OBS], [64], [64, 64], [64]
+    const float *policy_w, *policy_b;     // [A, 64], [A]   (NULL unless DO_P)
+    const float *critic_w, *critic_b;     // [1, 64], [1]   (NULL unless DO_V)
+};
+
+struct UpdArgs {
+    Net net;
+    const float *states;                  // [B, OBS]
+    const int *actions;                   // [B]
+    const float *old_lp, *old_v, *adv;    // [B]
+    const double *stats3;                 // advantage statistics of the minibatch (ppo_adv_stats), or NULL
+    float lo, hi, epsf;
+    float c_pi, c_v, c_ent;               // gradient of c_pi policy_loss + c_v value_loss - c_ent entropy
+    long B;
+    int norm_adv, clip_va;
+    float *partials;                      // [waves][P] per-wave gradient partials, parameter order (see grad_offsets)
+    double *scal;                         // [waves][NSCAL]
+    int P;
+};
+
+// Offsets of the gradient tensors inside one partial row / the output buffer (floats):
+//   w1 [64, OBS], b1 [64], w2 [64, 64], b2 [64], policy_w [A, 64], policy_b [A], critic_w [64], critic_b [1]
+template <int OBS, int A, bool DO_P, bool DO_V> struct GradLayout {
+    static constexpr int W1 = 0, B1 = W1 + H * OBS, W2 = B1 + H, B2 = W2 + H * H, PW = B2 + H;
+    static constexpr int PB = PW + (DO_P ? A * H : 0), CW = PB + (DO_P ? A : 0), CB = CW + (DO_V ? H : 0);
+    static constexpr int P = CB + (DO_V ? 1 : 0);
+};
+
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
+}
+
+// tanh as in rollout.hip: 1 - 2 / (exp(2x) + 1) on the exp2 / rcp units (absolute error < 2e-7)
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    const float t = __builtin_amdgcn_exp2f(2.8853900817779268f * x);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+}
+
+// sum of x over the lane and its partner in the other half (lane ^ 32), in both
+__device__ __forceinline__ float sum_halves(float x)
+{
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // a: lower-half value, b: upper-half value
+    return a + b;
+}
+
+template <int OBS, int A, bool DO_P, bool DO_V>
+__global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
+{
+    using L = GradLayout<OBS, A, DO_P, DO_V>;
+    constexpr int S1 = ksteps(OBS);                    // 1 bias k-step + OBS / 2
+    constexpr int NHEAD = 4;                           // head rows: 0..A-1 logits, 3 = critic
+    static_assert(OBS % 2 == 0 && OBS < 8 && A <= 3, "layouts assume an even input width < 8 and <= 3 actions");
+    // ---- LDS: weight fragments (shared by the block), then the per-wave staging tiles
+    __shared__ float F1[S1][2][64];                    // layer 1, A operand: [k-step][row tile][lane]
+    __shared__ float F2[33][2][64];                    // layer 2
+    __shared__ float F2T[32][2][64];                   // layer 2 transposed (dh1 = W2^T dz2)
+    __shared__ __attribute__((aligned(16))) float HW[NHEAD][H];   // head rows, natural order
+    __shared__ float hbias[NHEAD];
+    __shared__ float SA[UPD_BLOCK / 64][H][SPAD];      // staging: [unit][sample]
+    __shared__ float SB[UPD_BLOCK / 64][H][SPAD];
+    __shared__ float SX[UPD_BLOCK / 64][8][SPAD];      // inputs (+ a row of ones at OBS) / head derivatives
+    const Net &n = a.net;
+    for (int k = threadIdx.x; k < S1 * 128; k += UPD_BLOCK) {
+        const int s = k >> 7, o = (k >> 6) & 1, l = k & 63, row = 32 * o + (l & 31);
+        float v;
+        if (s == 0) v = l < 32 ? n.b1[row] : 0.0f;
+        else v = n.w1[row * OBS + 2 * (s - 1) + (l >> 5)];
+        F1[s][o][l] = v;
+    }
+    for (int k = threadIdx.x; k < 33 * 128; k += UPD_BLOCK) {
+        const int s = k >> 7, o = (k >> 6) & 1, l = k & 63, row = 32 * o + (l & 31);
+        float v;
+        if (s == 0) v = l < 32 ? n.b2[row] : 0.0f;
+        else v = n.w2[row * H + unit((s - 1) >> 4, (s - 1) & 15, l >> 5)];
+        F2[s][o][l] = v;
+    }
+    for (int k = threadIdx.x; k < 32 * 128; k += UPD_BLOCK) {
+        const int s = k >> 7, o = (k >> 6) & 1, l = k & 63;
+        // A[row = h1 unit 32 o + (l & 31)][k = h2 unit unit(s >> 4, s & 15, l >> 5)] = W2[h2 unit][h1 unit]
+        F2T[s][o][l] = n.w2[unit(s >> 4, s & 15, l >> 5) * H + 32 * o + (l & 31)];
+    }
+    for (int k = threadIdx.x; k < NHEAD * H; k += UPD_BLOCK) {
+        const int j = k >> 6, u = k & 63;
+        float v = 0.0f;
+        if (DO_P && j < A) v = n.policy_w[j * H + u];
+        if (DO_V && j == 3) v = n.critic_w[u];
+        HW[j][u] = v;
+    }
+    if (threadIdx.x < NHEAD) {
+        float v = 0.0f;
+        if (DO_P && (int)threadIdx.x < A) v = n.policy_b[threadIdx.x];
+        if (DO_V && threadIdx.x == 3) v = n.critic_b[0];
+        hbias[threadIdx.x] = v;
+    }
+    __syncthreads();                                   // the only barrier: waves are independent from here on
+
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31, wv = threadIdx.x >> 6;
+    const float one = half == 0 ? 1.0f : 0.0f;
+    float(*sa)[SPAD] = SA[wv];
+    float(*sb)[SPAD] = SB[wv];
+    float(*sx)[SPAD] = SX[wv];
+    const LossConsts c = loss_consts(a.stats3, a.norm_adv, a.clip_va, a.lo, a.hi, a.epsf, a.B);
+
+    // gradient accumulators over all of this wave's samples
+    f32x16 gW2[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};   // [row tile: h2 unit][col tile: h1 unit]
+    f32x16 gW1[2] = {zero16(), zero16()};                              // [row tile: h1 unit], cols: input i (OBS = bias)
+    f32x16 gWh[2] = {zero16(), zero16()};                              // rows: head j, [col tile: h2 unit]
+    float gb2[2][16];                                                  // column sums of dz2, this lane's samples
+    float gbh[NHEAD] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gb2[o][r] = 0.0f;
+    double acc[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0};
+
+    const long tiles = (a.B + 31) / 32;
+    const long wave_id = (long)blockIdx.x * (UPD_BLOCK / 64) + wv, nwaves = (long)gridDim.x * (UPD_BLOCK / 64);
+    for (long t = wave_id; t < tiles; t += nwaves) {
+        const long i = t * 32 + col;
+        const bool valid = i < a.B;
+        const long ic = valid ? i : a.B - 1;
+        float x[OBS];
+#pragma unroll
+        for (int k = 0; k < OBS; ++k) x[k] = a.states[ic * OBS + k];
+        const int act = a.actions[ic];
+        const float old_lp = a.old_lp[ic], old_v = a.old_v[ic], adv = a.adv[ic];
+
+        // ---- forward
+        f32x16 h1[2], h2[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) h1[o] = UPD_MFMA(F1[0][o][lane], one, zero16());
+#pragma unroll
+        for (int s = 1; s < S1; ++s) {
+            const float b = half ? x[2 * (s - 1) + 1] : x[2 * (s - 1)];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) h1[o] = UPD_MFMA(F1[s][o][lane], b, h1[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[o][r] = fast_tanh(h1[o][r]);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) h2[o] = UPD_MFMA(F2[0][o][lane], one, zero16());
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) h2[o] = UPD_MFMA(F2[1 + k][o][lane], h1[k >> 4][k & 15], h2[o]);
+        }
+        float p[NHEAD] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int u0 = unit(o, 4 * r4, 0);             // units 4 r4 .. 4 r4 + 3 of this lane half are adjacent
+                float hv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = h2[o][4 * r4 + q] = fast_tanh(h2[o][4 * r4 + q]);
+#pragma unroll
+                for (int j = 0; j < NHEAD; ++j) {
+                    if ((DO_P && j < A) || (DO_V && j == 3)) {
+                        const float4 w = *reinterpret_cast<const float4 *>(&HW[j][u0 + 4 * half]);
+                        p[j] = __builtin_fmaf(hv[0], w.x, p[j]);
+                        p[j] = __builtin_fmaf(hv[1], w.y, p[j]);
+                        p[j] = __builtin_fmaf(hv[2], w.z, p[j]);
+                        p[j] = __builtin_fmaf(hv[3], w.w, p[j]);
+                    }
+                }
+            }
+        float out[NHEAD] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NHEAD; ++j)
+            if ((DO_P && j < A) || (DO_V && j == 3)) out[j] = sum_halves(p[j]) + hbias[j];
+
+        // ---- loss and its derivative wrt the head outputs (both lane halves compute their sample's)
+        float dout[NHEAD] = {0.f, 0.f, 0.f, 0.f};
+        float rho = 1.0f, H_ent = 0.0f;
+        if (DO_P) {
+            float lg[A];
+#pragma unroll
+            for (int k = 0; k < A; ++k) lg[k] = out[k];
+            Categorical<A> cat;
+            cat.from_logits(lg, act);
+            rho = expf(cat.new_lp - old_lp);                                   // :595
+            H_ent = cat.H;
+            const SampleOut o = loss_sample(c, rho, adv, old_v, DO_V ? out[3] : old_v);
+            const float g_lp = o.g_rho * rho;                                  // d policy_loss / d new_lp
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                const float g_pl = g_lp * ((k == act ? 1.0f : 0.0f) - cat.pr[k]);
+                const float g_en = -cat.pr[k] * (cat.lp[k] + cat.H) * c.invB;   // d mean(H) / d logit_k
+                dout[k] = a.c_pi * g_pl - a.c_ent * g_en;
+            }
+            if (DO_V) dout[3] = a.c_v * o.g_v;
+            if (valid && half == 0) {
+                acc[0] += (double)o.m;
+                acc[2] += (double)o.clipped;
+                acc[3] += (double)o.kl;
+                acc[4] += (double)cat.H;
+                if (DO_V) acc[1] += (double)o.vterm;
+            }
+        } else {
+            const SampleOut o = loss_sample(c, 1.0f, adv, old_v, out[3]);
+            dout[3] = a.c_v * o.g_v;
+            if (valid && half == 0) acc[1] += (double)o.vterm;
+        }
+        (void)H_ent;
+        if (!valid) {
+#pragma unroll
+            for (int j = 0; j < NHEAD; ++j) dout[j] = 0.0f;
+        }
+        if (half == 0) {
+#pragma unroll
+            for (int j = 0; j < NHEAD; ++j) gbh[j] += dout[j];
+        }
+
+        // ---- dz2 = (Whead^T dout) (1 - h2^2)
+        f32x16 dz2[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int u0 = unit(o, 4 * r4, 0) + 4 * half;
+                float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NHEAD; ++j) {
+                    if ((DO_P && j < A) || (DO_V && j == 3)) {
+                        const float4 w = *reinterpret_cast<const float4 *>(&HW[j][u0]);
+                        d[0] = __builtin_fmaf(w.x, dout[j], d[0]);
+                        d[1] = __builtin_fmaf(w.y, dout[j], d[1]);
+                        d[2] = __builtin_fmaf(w.z, dout[j], d[2]);
+                        d[3] = __builtin_fmaf(w.w, dout[j], d[3]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float h = h2[o][4 * r4 + q];
+                    const float z = d[q] * (1.0f - h * h);
+                    dz2[o][4 * r4 + q] = z;
+                    gb2[o][4 * r4 + q] += z;
+                }
+            }
+
+        // ---- dW2 += dz2 h1^T: transpose both through the staging tiles, samples become the k dimension
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sa[unit(o, r, half)][col] = dz2[o][r];
+                sb[unit(o, r, half)][col] = h1[o][r];
+            }
+        __builtin_amdgcn_wave_barrier();               // (compiler ordering only: a wave's LDS operations execute in order)
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int s = 2 * j + half;
+            const float a0 = sa[col][s], a1 = sa[32 + col][s], b0 = sb[col][s], b1 = sb[32 + col][s];
+            gW2[0][0] = UPD_MFMA(a0, b0, gW2[0][0]);
+            gW2[0][1] = UPD_MFMA(a0, b1, gW2[0][1]);
+            gW2[1][0] = UPD_MFMA(a1, b0, gW2[1][0]);
+            gW2[1][1] = UPD_MFMA(a1, b1, gW2[1][1]);
+        }
+
+        __builtin_amdgcn_wave_barrier();
+        // ---- dh1 = W2^T dz2 (register-chained), dz1 = dh1 (1 - h1^2)
+        f32x16 dz1[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) dz1[o] = UPD_MFMA(F2T[k][o][lane], dz2[k >> 4][k & 15], dz1[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float h = h1[o][r];
+                dz1[o][r] = dz1[o][r] * (1.0f - h * h);
+            }
+
+        // ---- dW1 (and db1 in column OBS) += dz1 [x, 1]^T
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[unit(o, r, half)][col] = dz1[o][r];
+        if (half == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sx[k][col] = k < OBS ? x[k] : (k == OBS ? 1.0f : 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int s = 2 * j + half;
+            const float a0 = sa[col][s], a1 = sa[32 + col][s];
+            const float b = col < 8 ? sx[col & 7][s] : 0.0f;
+            gW1[0] = UPD_MFMA(a0, b, gW1[0]);
+            gW1[1] = UPD_MFMA(a1, b, gW1[1]);
+        }
+
+        __builtin_amdgcn_wave_barrier();
+        // ---- head weight gradients: rows = head j, columns = h2 units
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sb[unit(o, r, half)][col] = h2[o][r];
+        if (half == 0) {
+#pragma unroll
+            for (int j = 0; j < NHEAD; ++j) sx[j][col] = dout[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int s = 2 * j + half;
+            const float av = col < NHEAD ? sx[col & 3][s] : 0.0f;
+            const float b0 = sb[col][s], b1 = sb[32 + col][s];
+            gWh[0] = UPD_MFMA(av, b0, gWh[0]);
+            gWh[1] = UPD_MFMA(av, b1, gWh[1]);
+        }
+    }
+
+    // ---- this wave's partials, in the parameters' own layout
+    float *g = a.partials + (size_t)wave_id * a.P;
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = unit(ut, r, half);
+#pragma unroll
+            for (int vt = 0; vt < 2; ++vt) g[L::W2 + u * H + 32 * vt + col] = gW2[ut][vt][r];
+            if (col < OBS) g[L::W1 + u * OBS + col] = gW1[ut][r];
+            if (col == OBS) g[L::B1 + u] = gW1[ut][r];
+        }
+    // column sums kept per lane: add the 32 samples (lanes of one half)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = gb2[o][r];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (col == 0) g[L::B2 + unit(o, r, half)] = v;
+        }
+    // head rows: D row j = register j of the lower lane half
+    if (half == 0) {
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            if (DO_P) {
+#pragma unroll
+                for (int j = 0; j < A; ++j) g[L::PW + j * H + 32 * vt + col] = gWh[vt][j];
+            }
+            if (DO_V) g[L::CW + 32 * vt + col] = gWh[vt][3];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NHEAD; ++j) {
+        float v = gbh[j];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) {
+            if (DO_P && j < A) g[L::PB + j] = v;
+            if (DO_V && j == 3) g[L::CB] = v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NSCAL; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NSCAL; ++k) a.scal[(size_t)wave_id * NSCAL + k] = acc[k];
+    }
+}
+
+// grads[p] = sum over the waves' partial rows, f64, in a fixed order (deterministic): a workgroup takes
+// 64 consecutive parameters (coalesced row reads), its 16 waves each add every 16th row, and the 16
+// sums are added in wave order.  Block 0 also finishes the loss scalars.
+constexpr int RED_GROUPS = 16;
+__global__ void __launch_bounds__(64 * RED_GROUPS) k_update_reduce(const float *partials, const double *scal, int nwaves, int P,
+                                                                 long B, float *grads, float *out5, int do_p, int do_v)
+{
+    __shared__ double part[RED_GROUPS][64];
+    const int px = threadIdx.x & 63, ry = threadIdx.x >> 6, p = blockIdx.x * 64 + px;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;          // four independent chains: loads in flight
+    if (p < P) {
+        int w = ry;
+        for (; w + 3 * RED_GROUPS < nwaves; w += 4 * RED_GROUPS) {
+            s0 += (double)partials[(size_t)w * P + p];
+            s1 += (double)partials[(size_t)(w + RED_GROUPS) * P + p];
+            s2 += (double)partials[(size_t)(w + 2 * RED_GROUPS) * P + p];
+            s3 += (double)partials[(size_t)(w + 3 * RED_GROUPS) * P + p];
+        }
+        for (; w < nwaves; w += RED_GROUPS) s0 += (double)partials[(size_t)w * P + p];
+    }
+    part[ry][px] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && p < P) {
+        double s = 0.0;
+        for (int g = 0; g < RED_GROUPS; ++g) s += part[g][px];
+        grads[p] = (float)s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < NSCAL) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += scal[(size_t)w * NSCAL + threadIdx.x];
+        const double n = (double)B;
+        const int k = threadIdx.x;
+        // out5 = {policy_loss, value_loss, clip_frac, kl_div, entropy}; entries the launch does not produce are left alone
+        if (k == 0 && do_p) out5[0] = (float)(-s / n);
+        if (k == 1 && do_v) out5[1] = (float)(0.5 * s / n);
+        if (k == 2 && do_p) out5[2] = (float)(s / n);
+        if (k == 3 && do_p) out5[3] = (float)(s / n);
+        if (k == 4 && do_p) out5[4] = (float)(s / n);
+    }
+}
+
+inline int upd_blocks(long B)
+{
+    const long tiles = (B + 31) / 32, per_block = UPD_BLOCK / 64;
+    long blocks = (tiles + per_block - 1) / per_block;
+    if (blocks > UPD_MAX_BLOCKS) blocks = UPD_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <int OBS, int A, bool DO_P, bool DO_V>
+int launch_update(UpdArgs a, float *grads, float *out5, void *workspace, size_t workspace_bytes, hipStream_t s)
+{
+    using L = GradLayout<OBS, A, DO_P, DO_V>;
+    const int blocks = upd_blocks(a.B), nwaves = blocks * (UPD_BLOCK / 64);
+    a.P = L::P;
+    const size_t part_bytes = ((size_t)nwaves * L::P * sizeof(float) + 255) / 256 * 256;
+    PPO_REQUIRE(workspace_bytes >= part_bytes + (size_t)nwaves * NSCAL * sizeof(double));
+    a.partials = static_cast<float *>(workspace);
+    a.scal = reinterpret_cast<double *>(static_cast<char *>(workspace) + part_bytes);
+    hipLaunchKernelGGL((k_update<OBS, A, DO_P, DO_V>), dim3(blocks), dim3(UPD_BLOCK), 0, s, a);
+    int rc = ppo_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_update_reduce, dim3((L::P + 63) / 64), dim3(64 * RED_GROUPS), 0, s, a.partials, a.scal, nwaves, L::P, a.B,
+                       grads, out5, DO_P ? 1 : 0, DO_V ? 1 : 0);
+    return ppo_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ppo_dense_update_workspace_bytes(void)
+{
+    // the largest gradient row (OBS = 6, A = 3, both heads) for every wave of the largest grid, plus the scalars
+    const size_t waves = (size_t)UPD_MAX_BLOCKS * (UPD_BLOCK / 64);
+    return (waves * (size_t)GradLayout<6, 3, true, true>::P * sizeof(float) + 255) / 256 * 256 + waves * NSCAL * sizeof(double);
+}
+
+size_t ppo_dense_update_grad_floats(int obs_dim, int num_actions, int heads)
+{
+    if ((obs_dim != 4 && obs_dim != 6) || (num_actions != 2 && num_actions != 3) || heads < 1 || heads > 3) return 0;
+    const bool p = heads & 1, v = heads & 2;
+    return (size_t)(H * obs_dim + H + H * H + H + (p ? num_actions * H + num_actions : 0) + (v ? H + 1 : 0));
+}
+
+int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float *w1, const float *b1, const float *w2,
+                           const float *b2, const float *policy_w, const float *policy_b, const float *critic_w,
+                           const float *critic_b, const float *states, const int *actions, const float *old_lp,
+                           const float *old_v, const float *adv, const double *stats3, double clip, int norm_adv,
+                           int clip_va, long B, double c_pi, double c_v, double c_ent, float *out5, float *grads,
+                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    PPO_REQUIRE((obs_dim == 4 || obs_dim == 6) && (num_actions == 2 || num_actions == 3));
+    PPO_REQUIRE(heads >= 1 && heads <= 3 && B >= 1);
+    const bool do_p = heads & 1, do_v = heads & 2;
+    PPO_REQUIRE(w1 && b1 && w2 && b2 && states && old_v && adv && out5 && grads && workspace);
+    PPO_REQUIRE(!do_p || (policy_w && policy_b && actions && old_lp));
+    PPO_REQUIRE(!do_v || (critic_w && critic_b));
+    PPO_REQUIRE(!norm_adv || stats3);
+    PPO_REQUIRE(ppo_aligned(workspace, 8) && ppo_aligned(grads, 4));
+    UpdArgs a{};
+    a.net = Net{w1, b1, w2, b2, policy_w, policy_b, critic_w, critic_b};
+    a.states = states; a.actions = actions ? actions : reinterpret_cast<const int *>(states);
+    a.old_lp = old_lp ? old_lp : old_v; a.old_v = old_v; a.adv = adv; a.stats3 = stats3;
+    a.lo = (float)(1.0 - clip); a.hi = (float)(1.0 + clip); a.epsf = (float)clip;
+    a.c_pi = (float)c_pi; a.c_v = (float)c_v; a.c_ent = (float)c_ent;
+    a.B = B; a.norm_adv = norm_adv; a.clip_va = clip_va;
+    hipStream_t s = (hipStream_t)stream;
+#define UPD_CASE(OBS_, A_)                                                                                             \
+    if (obs_dim == OBS_ && num_actions == A_) {                                                                        \
+        if (do_p && do_v) return launch_update<OBS_, A_, true, true>(a, grads, out5, workspace, workspace_bytes, s);   \
+        if (do_p) return launch_update<OBS_, A_, true, false>(a, grads, out5, workspace, workspace_bytes, s);          \
+        return launch_update<OBS_, A_, false, true>(a, grads, out5, workspace, workspace_bytes, s);                    \
+    }
+    UPD_CASE(4, 2) UPD_CASE(4, 3) UPD_CASE(6, 2) UPD_CASE(6, 3)
+#undef UPD_CASE
+    return (int)hipErrorInvalidValue;
+}
+
+}  // extern "C"

@@ -408,3 +408,71 @@ def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, l
     else:
         rc = lib.ppo_rollout_fused(*args, _stream())
     _lib.check(rc, "ppo_rollout_fused")
+
+
+# ---- fused dense update (csrc/update.hip) ------------------------------------------------------
+_update_ws = {}
+
+
+def dense_update_supported(agent) -> bool:
+    """The fused update covers the reference's dense Agent (64-64 tanh) with a Discrete head of 2 or 3
+    actions on 4 or 6 observations: CartPole and Acrobot."""
+    if agent.conv_net or not agent.discrete:
+        return False
+    w1 = agent.pi_backbone[0].weight
+    return (w1.is_cuda and w1.dtype == torch.float32 and tuple(w1.shape) in ((64, 4), (64, 6))
+            and agent.policy.weight.shape[0] in (2, 3))
+
+
+def dense_update_grads(agent, states, actions, old_log_probs, old_values, advantages, clip_ratio, norm_adv, clip_va_loss,
+                       c_pi, c_v, c_ent, stats3=None):
+    """ppo_dense_update_grads for a ppo_amd Agent: one launch per backbone.
+    Returns (out5, groups): out5 = device f32[5] {policy_loss, value_loss, clip_frac, kl_div, entropy};
+    groups = one list of (parameter, gradient tensor) per launch -- [all parameters] for a joint network,
+    [policy backbone + policy head, value backbone + critic head] for split networks -- the gradients being
+    views of one flat buffer per launch.  Gradient of  c_pi policy_loss + c_v value_loss - c_ent entropy."""
+    lib = _lib.load()
+    dev = states.device
+    B = int(states.shape[0])
+    obs, A = int(states.shape[1]), int(agent.policy.weight.shape[0])
+    for t, dt in ((states, torch.float32), (actions, torch.int32), (old_log_probs, torch.float32),
+                  (old_values, torch.float32), (advantages, torch.float32)):
+        assert t.is_cuda and t.dtype == dt and t.is_contiguous() and t.shape[0] == B, (t.dtype, t.shape)
+    if norm_adv and stats3 is None:
+        stats3 = adv_stats(advantages)
+    ws = _update_ws.get(dev)
+    if ws is None:
+        ws = _update_ws[dev] = torch.empty(lib.ppo_dense_update_workspace_bytes(), dtype=torch.uint8, device=dev)
+    out5 = torch.zeros(5, dtype=torch.float32, device=dev)
+    groups = []
+
+    def run(backbone, heads):
+        pairs = []
+        groups.append(pairs)
+        n = lib.ppo_dense_update_grad_floats(obs, A, heads)
+        g = torch.empty(n, dtype=torch.float32, device=dev)
+        l1, l2 = backbone[0], backbone[2]
+        pw, pb = (agent.policy.weight, agent.policy.bias) if heads & 1 else (None, None)
+        cw, cb = (agent.critic.weight, agent.critic.bias) if heads & 2 else (None, None)
+        params = [l1.weight, l1.bias, l2.weight, l2.bias] + ([pw, pb] if heads & 1 else []) + ([cw, cb] if heads & 2 else [])
+        for p in params:
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+        rc = lib.ppo_dense_update_grads(
+            obs, A, heads, l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(),
+            _ptr(pw), _ptr(pb), _ptr(cw), _ptr(cb), states.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr(),
+            old_values.data_ptr(), advantages.data_ptr(), _ptr(stats3), float(clip_ratio), int(bool(norm_adv)),
+            int(bool(clip_va_loss)), B, float(c_pi), float(c_v), float(c_ent), out5.data_ptr(), g.data_ptr(),
+            ws.data_ptr(), ws.numel(), _stream())
+        _lib.check(rc, "ppo_dense_update_grads")
+        at = 0
+        for p in params:
+            pairs.append((p, g[at:at + p.numel()].view_as(p)))
+            at += p.numel()
+        assert at == n
+
+    if agent.joint_net:
+        run(agent.pi_backbone, 3)
+    else:
+        run(agent.pi_backbone, 1)
+        run(agent.va_backbone, 2)
+    return out5, groups

@@ -626,6 +626,9 @@ class PPO:
         # Discrete heads: log-prob, entropy, ratio and losses in one kernel (ppo_loss_logits_fwd_bwd);
         # False keeps torch.distributions.Categorical in front of ppo_loss_fwd_bwd.
         self.fused_discrete_loss = True
+        # dense Discrete agents (CartPole / Acrobot): the whole minibatch step in one kernel; PPO_AMD_FUSED_UPDATE=0
+        # keeps the PyTorch MLP around the loss kernel
+        self.fused_dense_update = os.environ.get("PPO_AMD_FUSED_UPDATE", "1") != "0"
         self.minibatch_hook = None   # tests: called with a dict per minibatch (indices, losses) when set
         self._idle = False           # True while nothing of ours is queued on the device (set by a host read-back)
 
@@ -687,7 +690,11 @@ class PPO:
                       and actions.dtype == torch.int32)
         fused_gather = (dev.type == "cuda" and actions.dtype in (torch.int32, torch.float32)
                         and states.dtype == torch.float32)
-        self.last_paths = {"fused_head": bool(fused_head), "fused_gather": bool(fused_gather)}
+        # dense 64-64 tanh Agent + Discrete head: forward, loss, backward and weight gradients of a minibatch in
+        # one kernel (ppo_dense_update_grads) instead of the PyTorch MLP around the loss kernel
+        fused_update = (self.fused_dense_update and fused_head and fused_gather and ops.dense_update_supported(self.agent))
+        self.last_paths = {"fused_head": bool(fused_head), "fused_gather": bool(fused_gather),
+                           "fused_update": bool(fused_update)}
         for _epoch in range(num_epochs):
             perm = torch.randperm(data_size, device=dev)       # reference :575-576 (np.random.shuffle)
             for start in range(0, data_size, local_batch):
@@ -701,7 +708,13 @@ class PPO:
                 stats3 = None
                 if self.norm_adv and world > 1:                # keep minibatch normalisation global
                     stats3 = ppo_dist.merged_adv_stats(ops.adv_stats(mb_adv))
-                if fused_head:   # Categorical log-prob + entropy + ratio + losses in one pass (:186-216, :595-599)
+                if fused_update:
+                    out5, groups = ops.dense_update_grads(
+                        self.agent, mb_states, mb_actions, mb_log_probs, mb_values, mb_adv, clip_ratio, self.norm_adv,
+                        self.clip_va_loss, c_pi=lr_anneal, c_v=critic_coef * lr_anneal, c_ent=entropy_coef * lr_anneal,
+                        stats3=stats3)
+                    policy_loss, critic_loss, clip_frac, kl_div, entropy = out5.unbind(0)
+                elif fused_head:   # Categorical log-prob + entropy + ratio + losses in one pass (:186-216, :595-599)
                     logits, new_values = self.agent.policy_and_values(mb_states)
                     policy_loss, critic_loss, clip_frac, kl_div, entropy = ops.ppo_losses_discrete(
                         logits, mb_actions, new_values, mb_log_probs, mb_values, mb_adv, clip_ratio,
@@ -711,7 +724,17 @@ class PPO:
                     policy_loss, critic_loss, clip_frac, kl_div = ops.ppo_losses(
                         new_log_probs, new_values, mb_log_probs, mb_values, mb_adv, clip_ratio,
                         self.norm_adv, self.clip_va_loss, ratio_input=False, stats3=stats3)  # :595-599
-                if self.joint_network:                         # reference :602-609
+                if fused_update:                               # gradients are already there: :602-625 without backward()
+                    for k, (opt, grp) in enumerate(zip((self.pi_optimizer, self.va_optimizer), groups)):
+                        opt.zero_grad()
+                        for prm, grad in grp:
+                            prm.grad = grad
+                        ppo_dist.allreduce_grads(params)
+                        nn.utils.clip_grad_norm_(params, max_grad_norm)
+                        opt.step()
+                    if not self.joint_network:
+                        critic_loss = critic_coef * critic_loss
+                elif self.joint_network:                       # reference :602-609
                     total = (policy_loss + critic_coef * critic_loss - entropy_coef * entropy) * lr_anneal
                     self.pi_optimizer.zero_grad()
                     total.backward()
