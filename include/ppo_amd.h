@@ -350,8 +350,11 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
  *   heads = 3: joint network.  Split networks: one call with the policy backbone and heads = 1
  *   (policy_loss, entropy, clip_frac, kl_div), one with the value backbone and heads = 2.
  *   w1 .. critic_b: the nn.Linear tensors (row-major [out, in]); policy_* / critic_* may be NULL
- *   for a head that is not given.  states [B, obs] f32, actions [B] i32, old_lp / old_v / adv [B] f32
- *   (the gathered minibatch); stats3 as for ppo_loss_fwd_bwd.  obs_dim 4 or 6, num_actions 2 or 3.
+ *   for a head that is not given.  states [rows, obs] f32, actions [rows] i32, old_lp / old_v / adv
+ *   [rows] f32: the flattened rollout buffers; idx [B] i64: the rows that form the minibatch (the
+ *   slice of the shuffled indices, :575-588 -- the kernel gathers as it goes), or NULL for rows
+ *   0 .. B-1.  stats3: statistics of the MINIBATCH's advantages as for ppo_loss_fwd_bwd.
+ *   obs_dim 4 or 6, num_actions 2 or 3.
  * Arithmetic: exact f32 products (f32 MFMA), tanh = 1 - 2 / (exp(2x) + 1) on the exp2 / rcp units
  * (absolute error < 2e-7), per-sample loss terms as in ppo_loss_logits_fwd_bwd, gradient sums per
  * wave in f32 and across waves in f64 in a fixed order (run-to-run deterministic).  Agrees with
@@ -364,8 +367,9 @@ size_t ppo_dense_update_grad_floats(int obs_dim, int num_actions, int heads);
 int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float *w1, const float *b1,
                            const float *w2, const float *b2, const float *policy_w,
                            const float *policy_b, const float *critic_w, const float *critic_b,
-                           const float *states, const int *actions, const float *old_lp,
-                           const float *old_v, const float *adv, const double *stats3, double clip,
+                           const long *idx, const float *states, const int *actions,
+                           const float *old_lp, const float *old_v, const float *adv,
+                           const double *stats3, double clip,
                            int norm_adv, int clip_va, long B, double c_pi, double c_v, double c_ent,
                            float *out5, float *grads, void *workspace, size_t workspace_bytes,
                            void *stream);

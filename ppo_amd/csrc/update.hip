@@ -52,15 +52,16 @@ struct Net {                              // one backbone + the heads that hang 
 
 struct UpdArgs {
     Net net;
-    const float *states;                  // [B, OBS]
-    const int *actions;                   // [B]
-    const float *old_lp, *old_v, *adv;    // [B]
+    const long *idx;                      // [B] rows of the arrays below that form the minibatch, or NULL (rows 0 .. B-1)
+    const float *states;                  // [rows, OBS]
+    const int *actions;                   // [rows]
+    const float *old_lp, *old_v, *adv;    // [rows]
     const double *stats3;                 // advantage statistics of the minibatch (ppo_adv_stats), or NULL
     float lo, hi, epsf;
     float c_pi, c_v, c_ent;               // gradient of c_pi policy_loss + c_v value_loss - c_ent entropy
     long B;
     int norm_adv, clip_va;
-    float *partials;                      // [waves][P] per-wave gradient partials, parameter order (see grad_offsets)
+    float *partials;                      // [blocks][P] per-workgroup gradient partials, parameter order (GradLayout)
     double *scal;                         // [waves][NSCAL]
     int P;
 };
@@ -103,15 +104,22 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
     constexpr int S1 = ksteps(OBS);                    // 1 bias k-step + OBS / 2
     constexpr int NHEAD = 4;                           // head rows: 0..A-1 logits, 3 = critic
     static_assert(OBS % 2 == 0 && OBS < 8 && A <= 3, "layouts assume an even input width < 8 and <= 3 actions");
-    // ---- LDS: weight fragments (shared by the block), then the per-wave staging tiles
-    __shared__ float F1[S1][2][64];                    // layer 1, A operand: [k-step][row tile][lane]
-    __shared__ float F2[33][2][64];                    // layer 2
-    __shared__ float F2T[32][2][64];                   // layer 2 transposed (dh1 = W2^T dz2)
-    __shared__ __attribute__((aligned(16))) float HW[NHEAD][H];   // head rows, natural order
-    __shared__ float hbias[NHEAD];
-    __shared__ float SA[UPD_BLOCK / 64][H][SPAD];      // staging: [unit][sample]
-    __shared__ float SB[UPD_BLOCK / 64][H][SPAD];
-    __shared__ float SX[UPD_BLOCK / 64][8][SPAD];      // inputs (+ a row of ones at OBS) / head derivatives
+    // ---- LDS (one array, carved by hand: the gradient rows of the four waves are added in it at the
+    // end, over everything else): weight fragments shared by the block, then the per-wave staging tiles
+    constexpr int NW = UPD_BLOCK / 64;
+    constexpr int OFF_F1 = 0, OFF_F2 = OFF_F1 + S1 * 128, OFF_F2T = OFF_F2 + 33 * 128, OFF_HW = OFF_F2T + 32 * 128;
+    constexpr int OFF_HB = OFF_HW + NHEAD * H, OFF_SA = OFF_HB + 4, OFF_SB = OFF_SA + NW * H * SPAD;
+    constexpr int OFF_SX = OFF_SB + NW * H * SPAD, LDS_FLOATS = OFF_SX + NW * 8 * SPAD;
+    static_assert(LDS_FLOATS >= NW * L::P, "the waves' gradient rows must fit for the final addition");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float(*F1)[2][64] = reinterpret_cast<float(*)[2][64]>(lds + OFF_F1);     // layer 1, A operand: [k-step][row tile][lane]
+    float(*F2)[2][64] = reinterpret_cast<float(*)[2][64]>(lds + OFF_F2);     // layer 2
+    float(*F2T)[2][64] = reinterpret_cast<float(*)[2][64]>(lds + OFF_F2T);   // layer 2 transposed (dh1 = W2^T dz2)
+    float(*HW)[H] = reinterpret_cast<float(*)[H]>(lds + OFF_HW);             // head rows, natural order
+    float *hbias = lds + OFF_HB;
+    float(*SA)[H][SPAD] = reinterpret_cast<float(*)[H][SPAD]>(lds + OFF_SA);   // staging: [wave][unit][sample]
+    float(*SB)[H][SPAD] = reinterpret_cast<float(*)[H][SPAD]>(lds + OFF_SB);
+    float(*SX)[8][SPAD] = reinterpret_cast<float(*)[8][SPAD]>(lds + OFF_SX);   // inputs (+ a row of ones at OBS) / head derivatives
     const Net &n = a.net;
     for (int k = threadIdx.x; k < S1 * 128; k += UPD_BLOCK) {
         const int s = k >> 7, o = (k >> 6) & 1, l = k & 63, row = 32 * o + (l & 31);
@@ -168,15 +176,47 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 
     const long tiles = (a.B + 31) / 32;
     const long wave_id = (long)blockIdx.x * (UPD_BLOCK / 64) + wv, nwaves = (long)gridDim.x * (UPD_BLOCK / 64);
+    // A sample's inputs are fetched one tile ahead (and its row index two tiles ahead when the minibatch is
+    // given by idx): nothing in a tile's work touches global memory, so the loads fly under its MFMAs and
+    // the separate gather launch of the unfused path (and its write + re-read of the minibatch) is gone.
+    struct In {
+        float x[OBS];
+        int act;
+        float old_lp, old_v, adv;
+    };
+    const auto row_of = [&](long t) -> long {          // source row of this lane's sample of tile t (clamped)
+        long i = t * 32 + col;
+        if (i >= a.B) i = a.B - 1;
+        return a.idx ? a.idx[i] : i;
+    };
+    const auto fetch = [&](long row) {
+        In v;
+        if (OBS == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(a.states + row * 4);
+            v.x[0] = q.x; v.x[1] = q.y; v.x[2] = q.z; v.x[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < OBS; k += 2) {
+                const float2 q = *reinterpret_cast<const float2 *>(a.states + row * OBS + k);
+                v.x[k] = q.x; v.x[k + 1] = q.y;
+            }
+        }
+        v.act = a.actions[row];
+        v.old_lp = a.old_lp[row]; v.old_v = a.old_v[row]; v.adv = a.adv[row];
+        return v;
+    };
+    In nxt = fetch(row_of(wave_id < tiles ? wave_id : 0));
+    long row2 = row_of(wave_id + nwaves < tiles ? wave_id + nwaves : 0);
     for (long t = wave_id; t < tiles; t += nwaves) {
-        const long i = t * 32 + col;
-        const bool valid = i < a.B;
-        const long ic = valid ? i : a.B - 1;
+        const bool valid = t * 32 + col < a.B;
+        const In cur = nxt;
+        nxt = fetch(row2);
+        row2 = row_of(t + 2 * nwaves < tiles ? t + 2 * nwaves : 0);
         float x[OBS];
 #pragma unroll
-        for (int k = 0; k < OBS; ++k) x[k] = a.states[ic * OBS + k];
-        const int act = a.actions[ic];
-        const float old_lp = a.old_lp[ic], old_v = a.old_v[ic], adv = a.adv[ic];
+        for (int k = 0; k < OBS; ++k) x[k] = cur.x[k];
+        const int act = cur.act;
+        const float old_lp = cur.old_lp, old_v = cur.old_v, adv = cur.adv;
 
         // ---- forward
         f32x16 h1[2], h2[2];
@@ -368,8 +408,10 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
         }
     }
 
-    // ---- this wave's partials, in the parameters' own layout
-    float *g = a.partials + (size_t)wave_id * a.P;
+    // ---- this wave's partials, in the parameters' own layout, into LDS (every wave is done with the
+    // weights and its staging tiles); the four rows are then added in wave order: one row per workgroup
+    __syncthreads();
+    float *g = lds + wv * L::P;
 #pragma unroll
     for (int ut = 0; ut < 2; ++ut)
 #pragma unroll
@@ -411,6 +453,13 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
             if (DO_V && j == 3) g[L::CB] = v;
         }
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < L::P; k += UPD_BLOCK) {
+        float v = lds[k];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += lds[w * L::P + k];
+        a.partials[(size_t)blockIdx.x * L::P + k] = v;
+    }
 #pragma unroll
     for (int k = 0; k < NSCAL; ++k) acc[k] = wave_sum(acc[k]);
     if (lane == 0) {
@@ -423,21 +472,21 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 // 64 consecutive parameters (coalesced row reads), its 16 waves each add every 16th row, and the 16
 // sums are added in wave order.  Block 0 also finishes the loss scalars.
 constexpr int RED_GROUPS = 16;
-__global__ void __launch_bounds__(64 * RED_GROUPS) k_update_reduce(const float *partials, const double *scal, int nwaves, int P,
-                                                                 long B, float *grads, float *out5, int do_p, int do_v)
+__global__ void __launch_bounds__(64 * RED_GROUPS) k_update_reduce(const float *partials, const double *scal, int nrows, int nwaves,
+                                                                 int P, long B, float *grads, float *out5, int do_p, int do_v)
 {
     __shared__ double part[RED_GROUPS][64];
     const int px = threadIdx.x & 63, ry = threadIdx.x >> 6, p = blockIdx.x * 64 + px;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;          // four independent chains: loads in flight
     if (p < P) {
         int w = ry;
-        for (; w + 3 * RED_GROUPS < nwaves; w += 4 * RED_GROUPS) {
+        for (; w + 3 * RED_GROUPS < nrows; w += 4 * RED_GROUPS) {
             s0 += (double)partials[(size_t)w * P + p];
             s1 += (double)partials[(size_t)(w + RED_GROUPS) * P + p];
             s2 += (double)partials[(size_t)(w + 2 * RED_GROUPS) * P + p];
             s3 += (double)partials[(size_t)(w + 3 * RED_GROUPS) * P + p];
         }
-        for (; w < nwaves; w += RED_GROUPS) s0 += (double)partials[(size_t)w * P + p];
+        for (; w < nrows; w += RED_GROUPS) s0 += (double)partials[(size_t)w * P + p];
     }
     part[ry][px] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -446,11 +495,12 @@ __global__ void __launch_bounds__(64 * RED_GROUPS) k_update_reduce(const float *
         for (int g = 0; g < RED_GROUPS; ++g) s += part[g][px];
         grads[p] = (float)s;
     }
-    if (blockIdx.x == 0 && threadIdx.x < NSCAL) {
+    if (blockIdx.x == 0 && ry < NSCAL) {                      // wave k adds scalar k: a fixed partition, then a butterfly
         double s = 0.0;
-        for (int w = 0; w < nwaves; ++w) s += scal[(size_t)w * NSCAL + threadIdx.x];
+        for (int w = px; w < nwaves; w += 64) s += scal[(size_t)w * NSCAL + ry];
+        s = wave_sum(s);
         const double n = (double)B;
-        const int k = threadIdx.x;
+        const int k = px == 0 ? ry : -1;
         // out5 = {policy_loss, value_loss, clip_frac, kl_div, entropy}; entries the launch does not produce are left alone
         if (k == 0 && do_p) out5[0] = (float)(-s / n);
         if (k == 1 && do_v) out5[1] = (float)(0.5 * s / n);
@@ -475,14 +525,14 @@ int launch_update(UpdArgs a, float *grads, float *out5, void *workspace, size_t 
     using L = GradLayout<OBS, A, DO_P, DO_V>;
     const int blocks = upd_blocks(a.B), nwaves = blocks * (UPD_BLOCK / 64);
     a.P = L::P;
-    const size_t part_bytes = ((size_t)nwaves * L::P * sizeof(float) + 255) / 256 * 256;
+    const size_t part_bytes = ((size_t)blocks * L::P * sizeof(float) + 255) / 256 * 256;
     PPO_REQUIRE(workspace_bytes >= part_bytes + (size_t)nwaves * NSCAL * sizeof(double));
     a.partials = static_cast<float *>(workspace);
     a.scal = reinterpret_cast<double *>(static_cast<char *>(workspace) + part_bytes);
     hipLaunchKernelGGL((k_update<OBS, A, DO_P, DO_V>), dim3(blocks), dim3(UPD_BLOCK), 0, s, a);
     int rc = ppo_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_update_reduce, dim3((L::P + 63) / 64), dim3(64 * RED_GROUPS), 0, s, a.partials, a.scal, nwaves, L::P, a.B,
+    hipLaunchKernelGGL(k_update_reduce, dim3((L::P + 63) / 64), dim3(64 * RED_GROUPS), 0, s, a.partials, a.scal, blocks, nwaves, L::P, a.B,
                        grads, out5, DO_P ? 1 : 0, DO_V ? 1 : 0);
     return ppo_launch_status();
 }
@@ -495,7 +545,7 @@ size_t ppo_dense_update_workspace_bytes(void)
 {
     // the largest gradient row (OBS = 6, A = 3, both heads) for every wave of the largest grid, plus the scalars
     const size_t waves = (size_t)UPD_MAX_BLOCKS * (UPD_BLOCK / 64);
-    return (waves * (size_t)GradLayout<6, 3, true, true>::P * sizeof(float) + 255) / 256 * 256 + waves * NSCAL * sizeof(double);
+    return ((size_t)UPD_MAX_BLOCKS * GradLayout<6, 3, true, true>::P * sizeof(float) + 255) / 256 * 256 + waves * NSCAL * sizeof(double);
 }
 
 size_t ppo_dense_update_grad_floats(int obs_dim, int num_actions, int heads)
@@ -507,7 +557,7 @@ size_t ppo_dense_update_grad_floats(int obs_dim, int num_actions, int heads)
 
 int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float *w1, const float *b1, const float *w2,
                            const float *b2, const float *policy_w, const float *policy_b, const float *critic_w,
-                           const float *critic_b, const float *states, const int *actions, const float *old_lp,
+                           const float *critic_b, const long *idx, const float *states, const int *actions, const float *old_lp,
                            const float *old_v, const float *adv, const double *stats3, double clip, int norm_adv,
                            int clip_va, long B, double c_pi, double c_v, double c_ent, float *out5, float *grads,
                            void *workspace, size_t workspace_bytes, void *stream)
@@ -519,10 +569,10 @@ int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float 
     PPO_REQUIRE(!do_p || (policy_w && policy_b && actions && old_lp));
     PPO_REQUIRE(!do_v || (critic_w && critic_b));
     PPO_REQUIRE(!norm_adv || stats3);
-    PPO_REQUIRE(ppo_aligned(workspace, 8) && ppo_aligned(grads, 4));
+    PPO_REQUIRE(ppo_aligned(workspace, 8) && ppo_aligned(grads, 4) && ppo_aligned(states, obs_dim == 4 ? 16 : 8));
     UpdArgs a{};
     a.net = Net{w1, b1, w2, b2, policy_w, policy_b, critic_w, critic_b};
-    a.states = states; a.actions = actions ? actions : reinterpret_cast<const int *>(states);
+    a.idx = idx; a.states = states; a.actions = actions ? actions : reinterpret_cast<const int *>(states);
     a.old_lp = old_lp ? old_lp : old_v; a.old_v = old_v; a.adv = adv; a.stats3 = stats3;
     a.lo = (float)(1.0 - clip); a.hi = (float)(1.0 + clip); a.epsf = (float)clip;
     a.c_pi = (float)c_pi; a.c_v = (float)c_v; a.c_ent = (float)c_ent;

@@ -425,21 +425,26 @@ def dense_update_supported(agent) -> bool:
 
 
 def dense_update_grads(agent, states, actions, old_log_probs, old_values, advantages, clip_ratio, norm_adv, clip_va_loss,
-                       c_pi, c_v, c_ent, stats3=None):
+                       c_pi, c_v, c_ent, stats3=None, idx=None):
     """ppo_dense_update_grads for a ppo_amd Agent: one launch per backbone.
     Returns (out5, groups): out5 = device f32[5] {policy_loss, value_loss, clip_frac, kl_div, entropy};
     groups = one list of (parameter, gradient tensor) per launch -- [all parameters] for a joint network,
     [policy backbone + policy head, value backbone + critic head] for split networks -- the gradients being
-    views of one flat buffer per launch.  Gradient of  c_pi policy_loss + c_v value_loss - c_ent entropy."""
+    views of one flat buffer per launch.  Gradient of  c_pi policy_loss + c_v value_loss - c_ent entropy.
+    idx (int64 [B], optional): the minibatch is rows idx of the given (flattened rollout) tensors -- the kernel
+    gathers as it goes (reference src/ppo.py:582-588); the advantage statistics are those of the minibatch."""
     lib = _lib.load()
     dev = states.device
-    B = int(states.shape[0])
+    rows = int(states.shape[0])
+    B = rows if idx is None else int(idx.numel())
     obs, A = int(states.shape[1]), int(agent.policy.weight.shape[0])
     for t, dt in ((states, torch.float32), (actions, torch.int32), (old_log_probs, torch.float32),
                   (old_values, torch.float32), (advantages, torch.float32)):
-        assert t.is_cuda and t.dtype == dt and t.is_contiguous() and t.shape[0] == B, (t.dtype, t.shape)
+        assert t.is_cuda and t.dtype == dt and t.is_contiguous() and t.shape[0] == rows, (t.dtype, t.shape)
+    if idx is not None:
+        assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 1
     if norm_adv and stats3 is None:
-        stats3 = adv_stats(advantages)
+        stats3 = adv_stats(advantages if idx is None else advantages[idx])
     ws = _update_ws.get(dev)
     if ws is None:
         ws = _update_ws[dev] = torch.empty(lib.ppo_dense_update_workspace_bytes(), dtype=torch.uint8, device=dev)
@@ -459,7 +464,7 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
             assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
         rc = lib.ppo_dense_update_grads(
             obs, A, heads, l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(),
-            _ptr(pw), _ptr(pb), _ptr(cw), _ptr(cb), states.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr(),
+            _ptr(pw), _ptr(pb), _ptr(cw), _ptr(cb), _ptr(idx), states.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr(),
             old_values.data_ptr(), advantages.data_ptr(), _ptr(stats3), float(clip_ratio), int(bool(norm_adv)),
             int(bool(clip_va_loss)), B, float(c_pi), float(c_v), float(c_ent), out5.data_ptr(), g.data_ptr(),
             ws.data_ptr(), ws.numel(), _stream())

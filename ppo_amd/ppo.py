@@ -699,7 +699,9 @@ class PPO:
             perm = torch.randperm(data_size, device=dev)       # reference :575-576 (np.random.shuffle)
             for start in range(0, data_size, local_batch):
                 idx = perm[start:start + local_batch]          # last minibatch may be short (:581)
-                if fused_gather:                               # one launch for the five gathers (:582-588)
+                if fused_update:                               # the update kernel gathers as it goes
+                    mb_adv = advantages[idx] if self.norm_adv else None
+                elif fused_gather:                             # one launch for the five gathers (:582-588)
                     mb_states, mb_actions, mb_log_probs, mb_values, mb_adv = ops.minibatch_gather(
                         idx, states, actions, log_probs, values, advantages)
                 else:
@@ -709,10 +711,12 @@ class PPO:
                 if self.norm_adv and world > 1:                # keep minibatch normalisation global
                     stats3 = ppo_dist.merged_adv_stats(ops.adv_stats(mb_adv))
                 if fused_update:
+                    if self.norm_adv and stats3 is None:
+                        stats3 = ops.adv_stats(mb_adv)
                     out5, groups = ops.dense_update_grads(
-                        self.agent, mb_states, mb_actions, mb_log_probs, mb_values, mb_adv, clip_ratio, self.norm_adv,
+                        self.agent, states, actions, log_probs, values, advantages, clip_ratio, self.norm_adv,
                         self.clip_va_loss, c_pi=lr_anneal, c_v=critic_coef * lr_anneal, c_ent=entropy_coef * lr_anneal,
-                        stats3=stats3)
+                        stats3=stats3, idx=idx)
                     policy_loss, critic_loss, clip_frac, kl_div, entropy = out5.unbind(0)
                 elif fused_head:   # Categorical log-prob + entropy + ratio + losses in one pass (:186-216, :595-599)
                     logits, new_values = self.agent.policy_and_values(mb_states)

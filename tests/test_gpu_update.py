@@ -89,6 +89,27 @@ def test_fused_update_matches_autograd(kind, joint, B):
         assert seen == set(g64.keys())                  # every parameter with a gradient got one, and no other
 
 
+def test_fused_update_gathers_its_minibatch():
+    """idx given: the minibatch is rows idx of the flattened rollout tensors (reference src/ppo.py:582-588); same
+    result, bit for bit, as the gathered minibatch handed over directly."""
+    from ppo_amd import Agent, ops
+    from ppo_amd.envs import DeviceEnv
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for kind, joint in (("cartpole", 1), ("acrobot", 0)):
+        probe = DeviceEnv(kind)
+        agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=joint, device="cuda")
+        rows, B = 300000, 70001
+        full = _minibatch(kind, rows, gen)
+        idx = torch.randperm(rows, device="cuda", generator=gen)[:B].contiguous()
+        a5, a = ops.dense_update_grads(agent, *full[:5], 0.2, 1, 1, 1.0, 0.5, 0.01, idx=idx)
+        mb = [t[idx].contiguous() for t in full[:5]]
+        b5, b = ops.dense_update_grads(agent, *mb, 0.2, 1, 1, 1.0, 0.5, 0.01)
+        assert torch.equal(a5, b5)
+        for ga, gb in zip(a, b):
+            for (_, x), (_, y) in zip(ga, gb):
+                assert torch.equal(x, y)
+
+
 def test_fused_update_is_deterministic_and_masks_the_tail():
     from ppo_amd import Agent, ops
     from ppo_amd.envs import DeviceEnv
