@@ -166,7 +166,8 @@ def train_step_rates(kind, N, T, world, seed, updates=4):
         ppo.vec_env.close()
         del ppo
         torch.cuda.empty_cache()
-    out["config"] = f"{updates} updates, medians of the last {updates - 1}; num_epochs 1, batch_size T*N/4 (global), norm_adv 1, clip_va_loss 1"
+    out["config"] = (f"{updates} updates, medians of the last {updates - 1}; num_epochs 1, batch_size T*N/4 (global), norm_adv 1, "
+                     f"clip_va_loss 1; minibatch step = ppo_dense_update_grads (fused forward + loss + backward + weight gradients)")
     return out
 
 
