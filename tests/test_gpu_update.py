@@ -156,3 +156,35 @@ def test_trainer_with_fused_update_follows_the_pytorch_path(joint):
     d = np.abs(pa - pb)
     assert d.max() <= 2.2 * lr * steps, d.max()
     assert (d > 2e-5).mean() < 0.01, (d > 2e-5).mean()
+
+
+def test_fused_update_rejects_what_it_does_not_cover():
+    """Argument checks of the C entry point (hipErrorInvalidValue = 1, nothing launched), and NaN -- not a silent
+    zero log-prob -- for an action outside [0, A), like ppo_loss_logits_fwd_bwd (torch's Categorical raises)."""
+    from ppo_amd import Agent, _lib, ops
+    from ppo_amd.envs import DeviceEnv
+    lib = _lib.load()
+    assert lib.ppo_dense_update_grad_floats(5, 2, 3) == 0 and lib.ppo_dense_update_grad_floats(4, 4, 3) == 0
+    assert lib.ppo_dense_update_grad_floats(4, 2, 3) == 64 * 4 + 64 + 64 * 64 + 64 + 2 * 64 + 2 + 64 + 1
+    probe = DeviceEnv("cartpole")
+    agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    mb = _minibatch("cartpole", 4096, gen)
+    ws = torch.empty(lib.ppo_dense_update_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    g = torch.empty(lib.ppo_dense_update_grad_floats(4, 2, 3), dtype=torch.float32, device="cuda")
+    out5 = torch.zeros(5, device="cuda")
+    l1, l2 = agent.pi_backbone[0], agent.pi_backbone[2]
+    def call(obs=4, A=2, heads=3, B=4096, ws_bytes=None, policy_w=agent.policy.weight.data_ptr()):
+        return lib.ppo_dense_update_grads(
+            obs, A, heads, l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(), policy_w,
+            agent.policy.bias.data_ptr(), agent.critic.weight.data_ptr(), agent.critic.bias.data_ptr(), None,
+            mb[0].data_ptr(), mb[1].data_ptr(), mb[2].data_ptr(), mb[3].data_ptr(), mb[4].data_ptr(), None, 0.2, 0, 1, B,
+            1.0, 0.5, 0.01, out5.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel() if ws_bytes is None else ws_bytes, None)
+    assert call() == 0
+    for bad in (dict(obs=5), dict(A=4), dict(heads=0), dict(heads=4), dict(B=0), dict(ws_bytes=1024), dict(policy_w=None)):
+        assert call(**bad) == 1, bad
+    torch.cuda.synchronize()
+    actions = mb[1].clone()
+    actions[17] = 2                                                     # CartPole has actions 0 and 1
+    out, groups = ops.dense_update_grads(agent, mb[0], actions, mb[2], mb[3], mb[4], 0.2, 0, 1, 1.0, 0.5, 0.01)
+    assert torch.isnan(out[0]) and any(torch.isnan(gr).any() for _, gr in groups[0])
