@@ -260,7 +260,7 @@ template <int OBS_, int A_, bool JOINT_> struct NetF32 {
 // ---- network mode 1: f16 MFMA on two-piece splits (f32-grade products at 5x the MFMA rate) -----
 // v_mfma_f32_32x32x2_f32 costs 64 cycles per 2 k and does not overlap with the wave's other VALU
 // work (measured: SQ_VALU_MFMA_COEXEC_CYCLES = 0, issue gaps add up); v_mfma_f32_32x32x16_f16 does
-// 16 k in 32 cycles.  Every operand x is split as x = xh + xl with xh = f16(x) (toward zero) and
+// 16 k in 32 cycles.  Every operand x is split as x = xh + xl with xh = f16(x) (to nearest) and
 // xl = f16(x - xh) (the subtraction is exact), 22 significant bits in all -- xl may be an f16
 // subnormal, which the matrix cores honour: absolute error <= 2^-25 -- and a product becomes
 // xh wl + xl wh + xh wh: three MFMAs into one f32 accumulator (small terms first), the dropped
@@ -282,20 +282,16 @@ __device__ __forceinline__ f32x16 mfma16(const Frag16 &a, const Frag16 &b, f32x1
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
-// (a0, a1) -> packed f16 pairs of the high pieces (round toward zero) and of the low pieces: the
+// (a0, a1) -> packed f16 pairs of the high pieces (round to nearest) and of the low pieces: the
 // residual a - hi (exact in f32) rounded to f16, one v_fma_mixlo/mixhi_f16 each (src0 is read as
 // the f16 half of `hi`, the other operands as f32).  hipcc does not form these from C (it packs
 // the two residuals into v_pk_fma_f32 and converts separately: 5 instructions instead of 3).
 __device__ __forceinline__ void split2(float a0, float a1, uint32_t &hi, uint32_t &lo)
 {
-#ifdef PPO_SPLIT_HI_RTZ
-    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a0, a1));
-#else
     // round to nearest (v_cvt_pk_f16_f32, new in gfx950): the residual is at most half an f16 ulp, so
     // the low piece ends one bit further down than with v_cvt_pkrtz -- same instruction count
     using h2 = __attribute__((ext_vector_type(2))) _Float16;
     hi = __builtin_bit_cast(uint32_t, h2{(_Float16)a0, (_Float16)a1});
-#endif
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
 }
@@ -328,25 +324,8 @@ __device__ __forceinline__ f32x2 tanh2v_prescaled(float x0, float x1)
 
 struct RegW16 {
     Frag16 w1[2][2], w2[4][2][2];
-#ifdef PPO_B2_IN_LDS
-    // Tried and dropped (-DPPO_B2_IN_LDS): the layer-2 bias (the C operand of each tile's first MFMA)
-    // read from LDS when a tile starts -- 32 registers less to hold for the whole rollout, 119 -> 68
-    // v_accvgpr moves in the loop body, but the reads sit in front of the MFMA chain: 445 -> 462 us.
-    const float *b2s;                              // LDS copy as [op][r / 4][lane][r % 4], offset by 4 lane
-    __device__ __forceinline__ f32x16 bias2(int op) const
-    {
-        f32x16 b;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 x = *reinterpret_cast<const float4 *>(b2s + (op * 4 + q) * 256);
-            b[4 * q] = x.x; b[4 * q + 1] = x.y; b[4 * q + 2] = x.z; b[4 * q + 3] = x.w;
-        }
-        return b;
-    }
-#else
     f32x16 b2[2];
     __device__ __forceinline__ f32x16 bias2(int op) const { return b2[op]; }
-#endif
     __device__ __forceinline__ void load(const float *__restrict__ g, int lane)
     {
         const uint4 *v = reinterpret_cast<const uint4 *>(g);
@@ -366,12 +345,10 @@ struct RegW16 {
                     const uint4 x = v[BB16_W1 / 4 + ((j * 2 + op) * 2 + pc) * 64 + lane];
                     w2[j][op][pc] = Frag16{{x.x, x.y, x.z, x.w}};
                 }
-#ifndef PPO_B2_IN_LDS
 #pragma unroll
         for (int op = 0; op < 2; ++op)
 #pragma unroll
             for (int r = 0; r < 16; ++r) b2[op][r] = g[BB16_W1 + BB16_W2 + (op * 16 + r) * 64 + lane];
-#endif
     }
     __device__ __forceinline__ Frag16 get1(int op, int pc) const { return w1[op][pc]; }
     __device__ __forceinline__ Frag16 get2(int j, int op, int pc) const { return w2[j][op][pc]; }
@@ -539,14 +516,6 @@ template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
             if (DIFF && (jo >> 1) == 0) v = heads[k + 2 * 16 * 64] - v;   // row 0 <- row 1 - row 0
             shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = v;
         }
-#ifdef PPO_B2_IN_LDS
-        float *sb2 = shl + HL_WORDS;               // policy backbone's layer-2 bias, [op][r / 4][lane][r % 4]
-        for (int k = threadIdx.x; k < BB16_B2; k += ROLLOUT_BLOCK) {      // k = (op * 16 + r) * 64 + lane
-            const int l = k & 63, r = (k >> 6) & 15, op = k >> 10;
-            sb2[((op * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = params[BB16_W1 + BB16_W2 + k];
-        }
-        P.b2s = sb2 + 4 * lane;
-#endif
         __syncthreads();                           // the only barrier: waves are independent from here on
         V.p = smem;
         V.lane = lane;
