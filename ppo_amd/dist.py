@@ -56,6 +56,16 @@ def broadcast_params(module: torch.nn.Module, src: int = 0):
         off += n
 
 
+def _all_reduce(t: torch.Tensor):
+    """Sum over ranks, in place.  RCCL collectives are stream-ordered.  gloo on device tensors (only used to
+    rehearse several ranks on ONE GPU) stages through the host with its own threads and streams; with
+    several collectives outstanding behind queued kernels it deadlocked (both ranks inside all_reduce,
+    tools/dp_two_ranks.sh at 4 096 envs with split networks), so there the stream is drained first."""
+    if t.is_cuda and td.get_backend() == "gloo":
+        torch.cuda.synchronize()
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+
+
 def allreduce_grads(params):
     """Mean of gradients over ranks in ONE collective (flattened bucket)."""
     if not is_dist():
@@ -64,7 +74,7 @@ def allreduce_grads(params):
     if not with_grad:
         return
     flat = torch.cat([p.grad.reshape(-1) for p in with_grad])
-    td.all_reduce(flat, op=td.ReduceOp.SUM)
+    _all_reduce(flat)
     flat /= world_size()
     off = 0
     for p in with_grad:
@@ -82,7 +92,7 @@ def merged_adv_stats(stats3: torch.Tensor) -> torch.Tensor:
     # collective that both RCCL and gloo run on device tensors
     rows = stats3.new_zeros((world_size(), 3))
     rows[rank()] = stats3
-    td.all_reduce(rows, op=td.ReduceOp.SUM)
+    _all_reduce(rows)
     from .ops import merge_stats
     return merge_stats([(g[0], g[1], g[2]) for g in rows])
 
@@ -91,7 +101,7 @@ def mean_scalar(x: torch.Tensor) -> torch.Tensor:
     if not is_dist():
         return x
     y = x.clone()
-    td.all_reduce(y, op=td.ReduceOp.SUM)
+    _all_reduce(y)
     return y / world_size()
 
 

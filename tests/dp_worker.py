@@ -17,11 +17,12 @@ from ppo_amd.envs import DeviceEnv  # noqa: E402
 def main():
     out, num_envs, T, batch, updates = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     kind = sys.argv[6] if len(sys.argv) > 6 else "cartpole"
+    joint = int(sys.argv[7]) if len(sys.argv) > 7 else 1
     train_fn = lambda: DeviceEnv(kind)  # noqa: E731
     D.init_from_env()                       # backend from PPO_AMD_DIST_BACKEND (gloo: both ranks share the one GPU)
     rank, world = D.rank(), D.world_size()
     torch.manual_seed(100 + 7 * rank)       # different init per rank: broadcast_params must equalise
-    ppo = PPO(0.99, 0.95, 1, 1, 0, 1, True, seed=2025)
+    ppo = PPO(0.99, 0.95, 1, 1, 0, joint, True, seed=2025)
     rec = {"world": world, "rank": rank, "steps": [], "buffers": None, "init": None, "metrics": []}
 
     def hook(info):

@@ -33,7 +33,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(out, world, kind, N, BATCH):
+def _launch(out, world, kind, N, BATCH, joint=1):
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -44,7 +44,7 @@ def _launch(out, world, kind, N, BATCH):
             env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), PPO_AMD_DIST_BACKEND="gloo")
         env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-        procs.append(subprocess.Popen([sys.executable, "-u", WORKER, out, str(N), str(T), str(BATCH), str(UPDATES), kind],
+        procs.append(subprocess.Popen([sys.executable, "-u", WORKER, out, str(N), str(T), str(BATCH), str(UPDATES), kind, str(joint)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -114,3 +114,23 @@ def test_world2_training_equals_the_single_process_run(tmp_path, kind, N, BATCH)
     # the job-level rate uses the slowest rank's time: both ranks report the same figure
     for a, b in zip(r0["metrics"], r1["metrics"]):
         assert a["utils/env_steps_per_sec"] == b["utils/env_steps_per_sec"] > 0
+
+
+def test_world2_split_networks_with_the_fused_update(tmp_path):
+    """Split networks, two ranks, 4 096 envs: the fused minibatch step issues two gradient all-reduces per
+    minibatch (policy half, value half) with little host work in between.  (Over gloo on one shared GPU this
+    is the case that deadlocked inside all_reduce until dist._all_reduce drained the stream first.)  Both
+    ranks finish, hold bit-identical parameters after every optimiser step, and start from the world-1
+    run's rollout."""
+    N, BATCH = 4096, 4096 * T // 4
+    r0, r1 = _launch(str(tmp_path / "dps2"), 2, "cartpole", N, BATCH, joint=0)
+    (w1,) = _launch(str(tmp_path / "dps1"), 1, "cartpole", N, BATCH, joint=0)
+    assert len(r0["steps"]) == len(r1["steps"]) == len(w1["steps"]) > 0
+    for a, b in zip(r0["steps"], r1["steps"]):
+        assert torch.equal(a["params"], b["params"])
+    for k, whole in w1["buffers"].items():
+        assert torch.equal(torch.cat([r0["buffers"][k], r1["buffers"][k]], dim=1), whole), k
+    # first minibatch: the ranks' mean losses are those of the world-1 run's first minibatch only in distribution
+    # (different samples); the parameters after it must be close: same data, same update rule, 2 x 1/2 the samples
+    d = (r0["steps"][-1]["params"] - w1["steps"][-1]["params"]).abs()
+    assert float(d.max()) < 0.05
