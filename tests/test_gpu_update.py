@@ -89,6 +89,32 @@ def test_fused_update_matches_autograd(kind, joint, B):
         assert seen == set(g64.keys())                  # every parameter with a gradient got one, and no other
 
 
+def test_fused_update_at_the_bench_minibatch_size():
+    """B = 2 097 152 (BASELINE configs[1]: T N / 4), joint CartPole network, gathered through idx from the 8 M rows of
+    a rollout: same bars as above."""
+    from ppo_amd import Agent, ops
+    from ppo_amd.envs import DeviceEnv
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    torch.manual_seed(21)
+    probe = DeviceEnv("cartpole")
+    agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
+    rows, B = 128 * 65536, 2097152
+    full = _minibatch("cartpole", rows, gen)
+    idx = torch.randperm(rows, device="cuda", generator=gen)[:B].contiguous()
+    out5, groups = ops.dense_update_grads(agent, *full[:5], 0.2, 1, 1, 1.0, 0.5, 0.01, idx=idx)
+    mb = tuple(t[idx].contiguous() for t in full[:5]) + (2,)
+    want64, g64 = _autograd(agent, mb, 0.2, 1, 1, 1.0, 0.5, 0.01, torch.float64)
+    _, g32 = _autograd(agent, mb, 0.2, 1, 1, 1.0, 0.5, 0.01, torch.float32)
+    got = out5.cpu().numpy()
+    assert np.allclose(got[[0, 1, 4]], np.array(want64)[[0, 1, 4]], rtol=1e-5, atol=2e-7), (got, want64)
+    names = {id(p): n for n, p in agent.named_parameters()}
+    for p, g in groups[0]:
+        ref, t32 = g64[names[id(p)]], g32[names[id(p)]].double()
+        err = float((g.double() - ref).abs().max())
+        bar = 4.0 * float((t32 - ref).abs().max()) + 2e-6 * float(ref.abs().max()) + 1e-12
+        assert err <= bar, (names[id(p)], err, bar)
+
+
 def test_fused_update_gathers_its_minibatch():
     """idx given: the minibatch is rows idx of the flattened rollout tensors (reference src/ppo.py:582-588); same
     result, bit for bit, as the gathered minibatch handed over directly."""
