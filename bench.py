@@ -21,6 +21,12 @@ set inside the range where that mode measures as accurate as PyTorch's f32 forwa
 policy is inside it.  The same steps with exact f32 products forced are reported beside it
 (`value_with_exact_f32_products`) -- the figure to quote against the reference's f32 arithmetic.
 
+Clocks: after idling, this GPU needs ~40 ms of sustained work before its clocks settle, and the
+VALU-bound rollout kernel follows them (tools/rollout_phase.py).  `value` is therefore
+measured after --settle-steps (default 100) further untimed steps in front of the W warm-up steps --
+the regime a trainer lives in; the same W + K steps started from an idle GPU are measured first and
+reported as `value_from_idle_clocks`.
+
 After the timed region the same workload runs through PPO.train_step itself (a few updates, joint and
 split networks, 4 minibatches of T*N/4): `train_step` carries the reference's own three rates
 (src/ppo.py:559-560, :637-639) as the trainer reports them, under --gpus N with the RCCL gradient
@@ -61,6 +67,10 @@ def parse():
     # settled regime, and that is what the default invocation measures.
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=100)
+    p.add_argument("--settle-steps", type=int, default=100,
+                   help="untimed steps BEFORE the warm-up steps: ~50 ms of the same work, enough for the GPU's clocks to "
+                        "settle after idling (DESIGN.md 7); 0 = none.  The line also carries the figure measured from an "
+                        "idle GPU with the given --warmup only (value_from_idle_clocks)")
     p.add_argument("--env", default="cartpole", choices=["cartpole", "acrobot"])
     p.add_argument("--num-envs", type=int, default=65536, help="envs PER GPU")
     p.add_argument("--rollout-len", type=int, default=128)
@@ -231,17 +241,30 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        hot_path_step(True)        # same code path as the timed steps, so one-time costs land here
+    def timed_steps(record):
+        for _ in range(args.warmup):
+            hot_path_step(record)  # same code path as the timed steps, so one-time costs land here
+        ve._flush_stats()
+        barrier()
+        gae_events.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hot_path_step(record)
+        ve._flush_stats()          # the last rollout's episode statistics belong to the bracket too (src/ppo.py:404-417)
+        barrier()
+        return time.perf_counter() - t0
+
+    # From an idle GPU, with the given warm-up only: after idling this GPU needs ~40 ms of sustained work
+    # before its clocks settle (tools/rollout_phase.py), so a short run sits on that ramp.  Reported beside
+    # `value`, which is measured after --settle-steps more untimed steps: a trainer lives in that regime.
+    hot_path_step(False)           # one-time costs (allocations, first launches) are not the clock ramp
     ve._flush_stats()
     barrier()
-    gae_events.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hot_path_step(True)
-    ve._flush_stats()              # the last rollout's episode statistics belong to the bracket too (src/ppo.py:404-417)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    time.sleep(0.5)
+    elapsed_idle = timed_steps(False)
+    for _ in range(args.settle_steps):
+        hot_path_step(False)
+    elapsed = timed_steps(True)
     mode_used = {ops.NET_F32: "f32", ops.NET_F16_SPLIT: "f16_split"}[ve.net_mode_used]
     def max_over_ranks(x):
         if world > 1:
@@ -251,6 +274,7 @@ def main():
         return x
 
     elapsed = max_over_ranks(elapsed)
+    elapsed_idle = max_over_ranks(elapsed_idle)
     # The same K steps once more with the network's products done as exact f32 FMAs (PPO_NET_F32)
     # instead of the default two-piece f16 splits, reported beside `value` as the conservative figure.
     ve.net_mode = ops.NET_F32
@@ -311,6 +335,9 @@ def main():
                      "f16 splits of both operands, 22 bits each, f32 accumulate, chosen per parameter set only where that "
                      "measures as accurate as PyTorch's f32 forward -- tests/test_gpu_net_precision.py; exact f32 otherwise)",
             "data": "synthetic",
+            "clock_settle_steps": args.settle_steps,
+            "value_from_idle_clocks": total_steps / elapsed_idle,
+            "ms_per_step_from_idle_clocks": 1e3 * elapsed_idle / args.steps,
             "value_with_exact_f32_products": total_steps / elapsed_f32,
             "ms_per_step_with_exact_f32_products": 1e3 * elapsed_f32 / args.steps,
             "config": {"workload": f"{kind} batched stepping + GAE, N={N} envs/GPU x T={T}, dense 64-64 tanh policy "
