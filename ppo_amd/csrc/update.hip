@@ -25,8 +25,10 @@
 //              lane = unit: the wave transposes dz2 / h1 / dz1 / h2 through its own LDS staging tiles
 //              ([unit][sample], padded) and accumulates the 32 x 32 gradient tiles over all of its
 //              samples in MFMA accumulators; bias gradients are column sums kept per lane.
-// Every wave then writes its partial gradients in the parameters' own layout; k_update_reduce adds
-// the waves' partials in index order in f64 (deterministic) and finishes the loss scalars.
+// The four waves of a workgroup then add their partial gradients in LDS, in the parameters' own layout,
+// one row per workgroup goes to the workspace, and k_update_reduce adds the rows in a fixed order in
+// f64 (deterministic) and finishes the loss scalars.  The minibatch is gathered on the fly: a sample's
+// inputs are fetched through idx one tile ahead of their use.
 #include "common.h"
 #include "loss_core.h"
 #include "net_layout.h"
