@@ -83,6 +83,15 @@ def allreduce_grads(params):
         off += n
 
 
+def allreduce_flat(flat: torch.Tensor):
+    """Mean over ranks of a gradient bucket that is ALREADY one flat tensor (the fused update's gradients are
+    views of it): the collective alone, no concatenation and no copy back."""
+    if not is_dist():
+        return
+    _all_reduce(flat)
+    flat /= world_size()
+
+
 def merged_adv_stats(stats3: torch.Tensor) -> torch.Tensor:
     """All-gather {count, mean, M2} and merge (Chan et al.) so that every rank normalises its
     minibatch with the statistics of the GLOBAL minibatch."""

@@ -414,6 +414,11 @@ def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, l
 _update_ws = {}
 
 
+class GradGroup(list):
+    """[(parameter, gradient)] of one ppo_dense_update_grads launch; the gradients are views of `flat`."""
+    flat = None
+
+
 def dense_update_supported(agent) -> bool:
     """The fused update covers the reference's dense Agent (64-64 tanh) with a Discrete head of 2 or 3
     actions on 4 or 6 observations: CartPole and Acrobot."""
@@ -452,10 +457,10 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
     groups = []
 
     def run(backbone, heads):
-        pairs = []
+        pairs = GradGroup()
         groups.append(pairs)
         n = lib.ppo_dense_update_grad_floats(obs, A, heads)
-        g = torch.empty(n, dtype=torch.float32, device=dev)
+        g = pairs.flat = torch.empty(n, dtype=torch.float32, device=dev)
         l1, l2 = backbone[0], backbone[2]
         pw, pb = (agent.policy.weight, agent.policy.bias) if heads & 1 else (None, None)
         cw, cb = (agent.critic.weight, agent.critic.bias) if heads & 2 else (None, None)

@@ -736,7 +736,7 @@ class PPO:
                         opt.zero_grad()
                         for prm, grad in grp:
                             prm.grad = grad
-                        ppo_dist.allreduce_grads(params)
+                        ppo_dist.allreduce_flat(grp.flat)       # the group's gradients are views of one bucket
                         nn.utils.clip_grad_norm_(params, max_grad_norm)
                         opt.step()
                     if not self.joint_network:
