@@ -40,6 +40,12 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 #define UPD_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
+// 16 x 16 tiles (k = 4 per instruction, half the cycles of the 32 x 32 form) for the two skinny gradient
+// products, dW1 (<= 7 useful columns) and the head rows (<= 4 useful rows): lane l supplies
+// A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15]; result register r of lane l is
+// D[row = 4 (l >> 4) + r][col = l & 15].
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+#define UPD_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 
 constexpr int UPD_BLOCK = 256;            // 4 waves, one per SIMD
 constexpr int UPD_MAX_BLOCKS = 256;       // one workgroup per CU (LDS: ~110 KB)
@@ -166,8 +172,9 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 
     // gradient accumulators over all of this wave's samples
     f32x16 gW2[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};   // [row tile: h2 unit][col tile: h1 unit]
-    f32x16 gW1[2] = {zero16(), zero16()};                              // [row tile: h1 unit], cols: input i (OBS = bias)
-    f32x16 gWh[2] = {zero16(), zero16()};                              // rows: head j, [col tile: h2 unit]
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 gW1[4] = {zero4, zero4, zero4, zero4};                       // [16-row tile: h1 unit], cols: input i (OBS = bias)
+    f32x4 gWh[4] = {zero4, zero4, zero4, zero4};                       // rows: head j, [16-col tile: h2 unit]
     float gb2[2][16];                                                  // column sums of dz2, this lane's samples
     float gbh[NHEAD] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -380,13 +387,13 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
             for (int k = 0; k < 8; ++k) sx[k][col] = k < OBS ? x[k] : (k == OBS ? 1.0f : 0.0f);
         }
         __builtin_amdgcn_wave_barrier();
+        const int c16 = lane & 15, g16 = lane >> 4;
 #pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-            const int s = 2 * j + half;
-            const float a0 = sa[col][s], a1 = sa[32 + col][s];
-            const float b = col < 8 ? sx[col & 7][s] : 0.0f;
-            gW1[0] = UPD_MFMA(a0, b, gW1[0]);
-            gW1[1] = UPD_MFMA(a1, b, gW1[1]);
+        for (int j = 0; j < 8; ++j) {
+            const int s = j + 8 * g16;                 // which samples share a k-step is free; this choice halves the bank conflicts
+            const float b = c16 < 8 ? sx[c16 & 7][s] : 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) gW1[rt] = UPD_MFMA16(sa[16 * rt + c16][s], b, gW1[rt]);
         }
 
         __builtin_amdgcn_wave_barrier();
@@ -401,12 +408,11 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-            const int s = 2 * j + half;
-            const float av = col < NHEAD ? sx[col & 3][s] : 0.0f;
-            const float b0 = sb[col][s], b1 = sb[32 + col][s];
-            gWh[0] = UPD_MFMA(av, b0, gWh[0]);
-            gWh[1] = UPD_MFMA(av, b1, gWh[1]);
+        for (int j = 0; j < 8; ++j) {
+            const int s = j + 8 * g16;
+            const float av = c16 < NHEAD ? sx[c16 & 3][s] : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) gWh[ct] = UPD_MFMA16(av, sb[16 * ct + c16][s], gWh[ct]);
         }
     }
 
@@ -421,9 +427,29 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
             const int u = unit(ut, r, half);
 #pragma unroll
             for (int vt = 0; vt < 2; ++vt) g[L::W2 + u * H + 32 * vt + col] = gW2[ut][vt][r];
-            if (col < OBS) g[L::W1 + u * OBS + col] = gW1[ut][r];
-            if (col == OBS) g[L::B1 + u] = gW1[ut][r];
         }
+    {
+        const int c16 = lane & 15, g16 = lane >> 4;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = 16 * rt + 4 * g16 + r;
+                if (c16 < OBS) g[L::W1 + u * OBS + c16] = gW1[rt][r];
+                if (c16 == OBS) g[L::B1 + u] = gW1[rt][r];
+            }
+        // head rows: D row j = register j of lanes 0..15
+        if (g16 == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (DO_P) {
+#pragma unroll
+                    for (int j = 0; j < A; ++j) g[L::PW + j * H + 16 * ct + c16] = gWh[ct][j];
+                }
+                if (DO_V) g[L::CW + 16 * ct + c16] = gWh[ct][3];
+            }
+        }
+    }
     // column sums kept per lane: add the 32 samples (lanes of one half)
 #pragma unroll
     for (int o = 0; o < 2; ++o)
@@ -434,17 +460,6 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
             for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
             if (col == 0) g[L::B2 + unit(o, r, half)] = v;
         }
-    // head rows: D row j = register j of the lower lane half
-    if (half == 0) {
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            if (DO_P) {
-#pragma unroll
-                for (int j = 0; j < A; ++j) g[L::PW + j * H + 32 * vt + col] = gWh[vt][j];
-            }
-            if (DO_V) g[L::CW + 32 * vt + col] = gWh[vt][3];
-        }
-    }
 #pragma unroll
     for (int j = 0; j < NHEAD; ++j) {
         float v = gbh[j];
