@@ -48,7 +48,12 @@ def broadcast_params(module: torch.nn.Module, src: int = 0):
     if not is_dist():
         return
     flat = torch.cat([p.data.reshape(-1) for p in module.parameters()])
-    td.broadcast(flat, src)
+    if _gloo_on_device(flat):             # see _all_reduce
+        h = flat.cpu()
+        td.broadcast(h, src)
+        flat.copy_(h)
+    else:
+        td.broadcast(flat, src)
     off = 0
     for p in module.parameters():
         n = p.numel()
@@ -56,13 +61,20 @@ def broadcast_params(module: torch.nn.Module, src: int = 0):
         off += n
 
 
+def _gloo_on_device(t: torch.Tensor) -> bool:
+    return t.is_cuda and td.get_backend() == "gloo"
+
+
 def _all_reduce(t: torch.Tensor):
-    """Sum over ranks, in place.  RCCL collectives are stream-ordered.  gloo on device tensors (only used to
-    rehearse several ranks on ONE GPU) stages through the host with its own threads and streams; with
-    several collectives outstanding behind queued kernels it deadlocked (both ranks inside all_reduce,
-    tools/dp_two_ranks.sh at 4 096 envs with split networks), so there the stream is drained first."""
-    if t.is_cuda and td.get_backend() == "gloo":
-        torch.cuda.synchronize()
+    """Sum over ranks, in place.  RCCL collectives are stream-ordered kernels.  gloo (only used to rehearse
+    several ranks on ONE GPU) is given host tensors: its device-tensor path stages through the host on
+    streams of its own, and the cross-stream waits that come with it deadlocked now and then when both
+    ranks shared one GPU (both ranks inside all_reduce; tests/test_gpu_dp_train.py, tools/dp_two_ranks.sh)."""
+    if _gloo_on_device(t):
+        h = t.cpu()                       # synchronous device -> host copy: the stream is drained
+        td.all_reduce(h, op=td.ReduceOp.SUM)
+        t.copy_(h)
+        return
     td.all_reduce(t, op=td.ReduceOp.SUM)
 
 
