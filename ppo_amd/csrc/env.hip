@@ -29,7 +29,8 @@ template <class Env> __global__ void __launch_bounds__(256) k_env_reset(EnvArgs 
     EnvRegs e;
     float obs[6];
     draw_reset(a, n, ep, u);
-    Env::reset(e.s, u, obs);
+    typename Env::Aux aux;
+    Env::reset(e.s, u, obs, aux);
     e.elapsed = 0; e.ep_ret = 0.0f; e.ep_len = 0;
     store_env(e, a, n);
     a.episode[n] = ep + 1;
@@ -43,7 +44,9 @@ template <class Env> __global__ void __launch_bounds__(256) k_env_step(EnvArgs a
     EnvRegs e;
     load_env(e, a, n);
     StepOut o;
-    env_transition<Env>(e, a.action[n], a, n, a.is_last, o);
+    typename Env::Aux aux;
+    Env::prime(e.s, aux);
+    env_transition<Env>(e, aux, a.action[n], a, n, a.is_last, o);
     a.reward[n] = o.reward;
     a.done[n] = o.done;
     a.trunc[n] = o.trunc;

@@ -58,8 +58,10 @@ __device__ __forceinline__ double div_by_total_mass(double x)
 // ---- CartPole-v1 ---------------------------------------------------------------------
 struct CartPole {
     static constexpr int OBS = 4;
+    struct Aux {};                                 // nothing derived from the state is worth carrying
+    __device__ static void prime(const double (&)[4], Aux &) {}
 
-    __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6])
+    __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &)
     {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -69,7 +71,7 @@ struct CartPole {
     }
 
     // returns terminated; reward is always 1.0
-    __device__ static bool step(double (&s)[4], int action, float (&obs)[6], float &reward)
+    __device__ static bool step(double (&s)[4], Aux &, int action, float (&obs)[6], float &reward)
     {
         constexpr double gravity = 9.8, masscart = 1.0, masspole = 0.1;
         constexpr double total_mass = masspole + masscart;
@@ -117,7 +119,13 @@ struct Acrobot {
     // way: 10 calls per step instead of 15.  The identities hold to ~3e-16 absolute (the reference's
     // own arguments theta - fl(pi/2) carry that much rounding), five orders below what the RK4 stages
     // amplify an ulp to (test_single_step_from_identical_states) and eleven below the 1e-5 bar.
+    // sin / cos of the state's own angles are what the observation is made of AND what the next
+    // step's first RK4 stage needs: they travel with the state (Aux) in the kernels that keep an env
+    // in registers across steps -- 8 calls per step; a kernel that loads the state primes them with
+    // the same two calls, so both forms compute the same numbers.
     struct Trig { double s1, c1, s2, c2; };
+    using Aux = Trig;
+    __device__ static void prime(const double (&s)[4], Aux &aux) { aux = trig_of(s[0], s[1]); }
     __device__ static Trig trig_of(double theta1, double theta2)
     {
         Trig t;
@@ -135,11 +143,11 @@ struct Acrobot {
         return t;
     }
 
-    __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6])
+    __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &aux)
     {
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] = (double)(float)(-0.1 + (0.1 - -0.1) * u[k]);  // .astype(float32)
-        write_obs(s, obs);
+        aux = write_obs(s, obs);
     }
 
     // 1 / d for d in [0.5, 5] (the two denominators of dsdt: d1 = 3.5 + cos(theta2) and
@@ -188,13 +196,13 @@ struct Acrobot {
         return x;
     }
 
-    __device__ static bool step(double (&s)[4], int action, float (&obs)[6], float &reward)
+    __device__ static bool step(double (&s)[4], Aux &aux, int action, float (&obs)[6], float &reward)
     {
         const double dt = 0.2 - 0;
         const double dt2 = dt / 2.0;
         const double torque = (double)(action - 1);
         double k1[4], k2[4], k3[4], k4[4], y[4];
-        dsdt(s, trig_of(s[0], s[1]), torque, k1);
+        dsdt(s, aux, torque, k1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k1[i];
         dsdt(y, trig_of(y[0], y[1]), torque, k2);
@@ -213,7 +221,7 @@ struct Acrobot {
         ns[3] = fmin(fmax(ns[3], -9 * PI), 9 * PI);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = ns[i];
-        const Trig t = write_obs(s, obs);
+        const Trig t = aux = write_obs(s, obs);
         const bool terminated = (-t.c1 - __builtin_fma(t.c1, t.c2, -(t.s1 * t.s2)) > 1.0);   // cos(ns[1] + ns[0])
         reward = terminated ? 0.0f : -1.0f;
         return terminated;
@@ -297,10 +305,10 @@ struct ResetAhead {
 // One transition of env n.  Follows gymnasium env.step -> TimeLimit -> RecordEpisodeStatistics and
 // the actor loop of the reference's rollout (src/ppo.py:342-388).
 template <class Env, bool DRAWS = true>
-__device__ __forceinline__ void env_transition(EnvRegs &e, int action, const EnvArgs &a, size_t n, int is_last,
+__device__ __forceinline__ void env_transition(EnvRegs &e, typename Env::Aux &aux, int action, const EnvArgs &a, size_t n, int is_last,
                                                StepOut &o, ResetAhead *ahead = nullptr)
 {
-    const bool terminated = Env::step(e.s, action, o.obs, o.reward);
+    const bool terminated = Env::step(e.s, aux, action, o.obs, o.reward);
     e.elapsed += 1;                                          // TimeLimit.step
     const bool truncated = e.elapsed >= MAX_EPISODE_STEPS;
     o.done = terminated ? 1 : 0;
@@ -338,12 +346,12 @@ __device__ __forceinline__ void env_transition(EnvRegs &e, int action, const Env
         for (int k = 0; k < 6; ++k) o.term[k] = o.obs[k];
         if (can_reset) {
             if (ahead) {
-                Env::reset(e.s, ahead->u, o.obs);
+                Env::reset(e.s, ahead->u, o.obs, aux);
                 ahead->have = false;
             } else {
                 double u[4];
                 draw_reset<DRAWS>(a, n, e.episode, u);
-                Env::reset(e.s, u, o.obs);
+                Env::reset(e.s, u, o.obs, aux);
             }
             e.episode += 1;
             e.elapsed = 0;

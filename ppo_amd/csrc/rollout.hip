@@ -554,6 +554,8 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 
     EnvRegs e;
     load_env(e, a.env, nn);
+    typename Env::Aux aux;                         // what the env derives from its state and carries along with it
+    Env::prime(e.s, aux);
     ResetAhead ahead;
     float obs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -618,7 +620,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 
         if (live) {
             if (!(ABLATE(a) & 2)) {
-                env_transition<Env, DRAWS>(e, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead);
+                env_transition<Env, DRAWS>(e, aux, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead);
             } else {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o.obs[k] = obs[k] + 1e-3f * (float)action;
