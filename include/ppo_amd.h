@@ -355,17 +355,22 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
  *   slice of the shuffled indices, :575-588 -- the kernel gathers as it goes), or NULL for rows
  *   0 .. B-1.  stats3: statistics of the MINIBATCH's advantages as for ppo_loss_fwd_bwd.
  *   obs_dim 4 or 6, num_actions 2 or 3.
- * Arithmetic: exact f32 products (f32 MFMA), tanh = 1 - 2 / (exp(2x) + 1) on the exp2 / rcp units
- * (absolute error < 2e-7), per-sample loss terms as in ppo_loss_logits_fwd_bwd, gradient sums per
- * wave in f32 and across waves in f64 in a fixed order (run-to-run deterministic).  Agrees with
- * PyTorch autograd of the same f32 network to f32 summation-order accuracy.
+ * Arithmetic: net_mode = PPO_NET_F32: exact f32 products (f32 MFMA) everywhere.  PPO_NET_F16_SPLIT: the
+ * two 64 x 64 products per sample (h2 = W2 h1 and dh1 = W2^T dz2) run as f16 MFMAs on two-piece splits
+ * of both operands, as in ppo_rollout_fused (same validity limits: ppo_rollout_pack_params'
+ * split_diag); dz2 is scaled per 32-sample tile by a power of two so that it fits f16's range
+ * whatever 1 / B and the value error are.  The weight-gradient sums are exact-f32 products in both
+ * modes.  tanh = 1 - 2 / (exp(2x) + 1) on the exp2 / rcp units (absolute error < 2e-7), per-sample
+ * loss terms as in ppo_loss_logits_fwd_bwd, gradient sums per wave in f32 and across waves in f64
+ * in a fixed order (run-to-run deterministic).  Agrees with PyTorch autograd of the same f32 network
+ * to f32 summation-order accuracy.
  * workspace: ppo_dense_update_workspace_bytes() bytes, 8-byte aligned; not shared between calls
  * that may overlap.
  */
 size_t ppo_dense_update_workspace_bytes(void);
 size_t ppo_dense_update_grad_floats(int obs_dim, int num_actions, int heads);
-int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float *w1, const float *b1,
-                           const float *w2, const float *b2, const float *policy_w,
+int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, int net_mode, const float *w1,
+                           const float *b1, const float *w2, const float *b2, const float *policy_w,
                            const float *policy_b, const float *critic_w, const float *critic_b,
                            const long *idx, const float *states, const int *actions,
                            const float *old_lp, const float *old_v, const float *adv,

@@ -35,6 +35,7 @@
 // work).  HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done, trunc).
 #include "env_core.h"
 #include "net_layout.h"
+#include "mfma_split.h"
 #ifdef PPO_ROLLOUT_ABLATE_BUILD
 #include <cstdlib>
 #endif
@@ -83,7 +84,6 @@ struct RolloutArgs {
 //   HL[j][o][r][l]  : Whead_j[unit(o, r, l >> 5)]
 // (ksteps, backbone_floats, HEAD_FLOATS, BB16_*: net_layout.h, shared with the pack kernel in pack.hip)
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units: 4 VALU instructions, no
 // branches (ocml's tanhf is two divergent branches of ~20).  exp2 overflow gives rcp(inf) = 0 ->
@@ -272,30 +272,6 @@ template <int OBS_, int A_, bool JOINT_> struct NetF32 {
 //   W2[j 4][op 2][piece 2][lane 64][4]   k-step j = 2 o_in + (r_in >> 3), element i = r_in & 7:
 //                                   W2[32 op + (l&31)][unit(o_in, r_in, l >> 5)]
 //   B2[op 2][r 16][lane 64] f32     b2[unit(op, r, l >> 5)]  (the C operand of the first k-step)
-struct Frag16 {
-    uint32_t w[4];
-};
-using h8 = __attribute__((ext_vector_type(8))) _Float16;
-
-__device__ __forceinline__ f32x16 mfma16(const Frag16 &a, const Frag16 &b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
-}
-
-// (a0, a1) -> packed f16 pairs of the high pieces (round to nearest) and of the low pieces: the
-// residual a - hi (exact in f32) rounded to f16, one v_fma_mixlo/mixhi_f16 each (src0 is read as
-// the f16 half of `hi`, the other operands as f32).  hipcc does not form these from C (it packs
-// the two residuals into v_pk_fma_f32 and converts separately: 5 instructions instead of 3).
-__device__ __forceinline__ void split2(float a0, float a1, uint32_t &hi, uint32_t &lo)
-{
-    // round to nearest (v_cvt_pk_f16_f32, new in gfx950): the residual is at most half an f16 ulp, so
-    // the low piece ends one bit further down than with v_cvt_pkrtz -- same instruction count
-    using h2 = __attribute__((ext_vector_type(2))) _Float16;
-    hi = __builtin_bit_cast(uint32_t, h2{(_Float16)a0, (_Float16)a1});
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
-}
-
 // tanh of an argument already multiplied by 2 log2(e)
 __device__ __forceinline__ float tanh_prescaled(float x2)
 {

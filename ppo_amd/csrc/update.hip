@@ -32,13 +32,13 @@
 #include "common.h"
 #include "loss_core.h"
 #include "net_layout.h"
+#include "mfma_split.h"
 
 using namespace ppo_net;
 using namespace ppo_loss;
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 #define UPD_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
 // 16 x 16 tiles (k = 4 per instruction, half the cycles of the 32 x 32 form) for the two skinny gradient
 // products, dW1 (<= 7 useful columns) and the head rows (<= 4 useful rows): lane l supplies
@@ -105,7 +105,38 @@ __device__ __forceinline__ float sum_halves(float x)
     return a + b;
 }
 
-template <int OBS, int A, bool DO_P, bool DO_V>
+// f16-split form of a register-chained 64 x 64 layer (F16 = true): the 32 registers a lane holds of a
+// [64 units][32 samples] tile -> the four k-steps' B operands, high and low pieces
+__device__ __forceinline__ void split_tile(const f32x16 (&v)[2], Frag16 (&bh)[4], Frag16 (&bl)[4])
+{
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) split2(v[o][r], v[o][r + 1], bh[2 * o + (r >> 3)].w[(r & 7) >> 1], bl[2 * o + (r >> 3)].w[(r & 7) >> 1]);
+}
+// acc[row tile] += W (fragments at `frag`: [k-step 4][row tile 2][piece 2][lane 64] x 16 B) times the split
+// operand: xh wl + xl wh first, xh wh last (small terms first), the two row tiles' chains interleaved
+__device__ __forceinline__ void chain16(const float *frag, int lane, const Frag16 (&bh)[4], const Frag16 (&bl)[4], f32x16 (&acc)[2])
+{
+    const uint4 *f = reinterpret_cast<const uint4 *>(frag);
+    const auto get = [&](int j, int o, int pc) {
+        const uint4 x = f[((j * 2 + o) * 2 + pc) * 64 + lane];
+        return Frag16{{x.x, x.y, x.z, x.w}};
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) acc[o] = mfma16(get(j, o, 1), bh[j], acc[o]);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) acc[o] = mfma16(get(j, o, 0), bl[j], acc[o]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) acc[o] = mfma16(get(j, o, 0), bh[j], acc[o]);
+}
+
+template <int OBS, int A, bool DO_P, bool DO_V, bool F16>
 __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 {
     using L = GradLayout<OBS, A, DO_P, DO_V>;
@@ -136,17 +167,42 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
         else v = n.w1[row * OBS + 2 * (s - 1) + (l >> 5)];
         F1[s][o][l] = v;
     }
-    for (int k = threadIdx.x; k < 33 * 128; k += UPD_BLOCK) {
-        const int s = k >> 7, o = (k >> 6) & 1, l = k & 63, row = 32 * o + (l & 31);
-        float v;
-        if (s == 0) v = l < 32 ? n.b2[row] : 0.0f;
-        else v = n.w2[row * H + unit((s - 1) >> 4, (s - 1) & 15, l >> 5)];
-        F2[s][o][l] = v;
-    }
-    for (int k = threadIdx.x; k < 32 * 128; k += UPD_BLOCK) {
-        const int s = k >> 7, o = (k >> 6) & 1, l = k & 63;
-        // A[row = h1 unit 32 o + (l & 31)][k = h2 unit unit(s >> 4, s & 15, l >> 5)] = W2[h2 unit][h1 unit]
-        F2T[s][o][l] = n.w2[unit(s >> 4, s & 15, l >> 5) * H + 32 * o + (l & 31)];
+    if constexpr (!F16) {
+        for (int k = threadIdx.x; k < 33 * 128; k += UPD_BLOCK) {
+            const int s = k >> 7, o = (k >> 6) & 1, l = k & 63, row = 32 * o + (l & 31);
+            float v;
+            if (s == 0) v = l < 32 ? n.b2[row] : 0.0f;
+            else v = n.w2[row * H + unit((s - 1) >> 4, (s - 1) & 15, l >> 5)];
+            F2[s][o][l] = v;
+        }
+        for (int k = threadIdx.x; k < 32 * 128; k += UPD_BLOCK) {
+            const int s = k >> 7, o = (k >> 6) & 1, l = k & 63;
+            // A[row = h1 unit 32 o + (l & 31)][k = h2 unit unit(s >> 4, s & 15, l >> 5)] = W2[h2 unit][h1 unit]
+            F2T[s][o][l] = n.w2[unit(s >> 4, s & 15, l >> 5) * H + 32 * o + (l & 31)];
+        }
+    } else {
+        // f16-split A operands of v_mfma_f32_32x32x16_f16 (layout of rollout.hip's W2): [k-step j 4][row tile 2]
+        // [piece 2][lane 64] x 8 f16; element i of lane l in k-step j is hidden unit unit(j >> 1, 8 (j & 1) + i, l >> 5)
+        // of the k dimension -- the order in which a 32 x 32 result tile's registers hold them.  F2H: W2 itself
+        // (rows = h2 units), F2TH: its transpose (rows = h1 units, dh1 = W2^T dz2).
+        for (int k = threadIdx.x; k < 2 * 4 * 2 * 64 * 4; k += UPD_BLOCK) {
+            const int q = k & 3, l = (k >> 2) & 63, o = (k >> 8) & 1, j = (k >> 9) & 3, tr = k >> 11;
+            const int row = 32 * o + (l & 31);
+            uint32_t hi = 0, lo = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = 2 * q + e, ku = unit(j >> 1, 8 * (j & 1) + i, l >> 5);
+                const float w = tr ? n.w2[ku * H + row] : n.w2[row * H + ku];
+                const _Float16 h = (_Float16)w, r = (_Float16)(w - (float)h);
+                hi |= (uint32_t)__builtin_bit_cast(unsigned short, h) << (16 * e);
+                lo |= (uint32_t)__builtin_bit_cast(unsigned short, r) << (16 * e);
+            }
+            uint32_t *dst = reinterpret_cast<uint32_t *>(lds + (tr ? OFF_F2T : OFF_F2));
+            dst[(((j * 2 + o) * 2 + 0) * 64 + l) * 4 + q] = hi;
+            dst[(((j * 2 + o) * 2 + 1) * 64 + l) * 4 + q] = lo;
+        }
+        // b2 as the C operand of the first k-step: [lane half][row tile][register]
+        for (int k = threadIdx.x; k < 64; k += UPD_BLOCK) lds[OFF_F2 + 4096 + k] = n.b2[unit((k >> 4) & 1, k & 15, k >> 5)];
     }
     for (int k = threadIdx.x; k < NHEAD * H; k += UPD_BLOCK) {
         const int j = k >> 6, u = k & 63;
@@ -241,12 +297,25 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
         for (int o = 0; o < 2; ++o)
 #pragma unroll
             for (int r = 0; r < 16; ++r) h1[o][r] = fast_tanh(h1[o][r]);
+        if constexpr (!F16) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o) h2[o] = UPD_MFMA(F2[0][o][lane], one, zero16());
+            for (int o = 0; o < 2; ++o) h2[o] = UPD_MFMA(F2[0][o][lane], one, zero16());
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < 32; ++k) {
 #pragma unroll
-            for (int o = 0; o < 2; ++o) h2[o] = UPD_MFMA(F2[1 + k][o][lane], h1[k >> 4][k & 15], h2[o]);
+                for (int o = 0; o < 2; ++o) h2[o] = UPD_MFMA(F2[1 + k][o][lane], h1[k >> 4][k & 15], h2[o]);
+            }
+        } else {
+            Frag16 bh[4], bl[4];
+            split_tile(h1, bh, bl);
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 b = *reinterpret_cast<const float4 *>(lds + OFF_F2 + 4096 + (half * 2 + o) * 16 + 4 * r4);
+                    h2[o][4 * r4] = b.x; h2[o][4 * r4 + 1] = b.y; h2[o][4 * r4 + 2] = b.z; h2[o][4 * r4 + 3] = b.w;
+                }
+            chain16(lds + OFF_F2, lane, bh, bl, h2);
         }
         float p[NHEAD] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -364,18 +433,48 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
         __builtin_amdgcn_wave_barrier();
         // ---- dh1 = W2^T dz2 (register-chained), dz1 = dh1 (1 - h1^2)
         f32x16 dz1[2] = {zero16(), zero16()};
+        if constexpr (!F16) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < 32; ++k) {
 #pragma unroll
-            for (int o = 0; o < 2; ++o) dz1[o] = UPD_MFMA(F2T[k][o][lane], dz2[k >> 4][k & 15], dz1[o]);
-        }
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float h = h1[o][r];
-                dz1[o][r] = dz1[o][r] * (1.0f - h * h);
+                for (int o = 0; o < 2; ++o) dz1[o] = UPD_MFMA(F2T[k][o][lane], dz2[k >> 4][k & 15], dz1[o]);
             }
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float h = h1[o][r];
+                    dz1[o][r] = dz1[o][r] * (1.0f - h * h);
+                }
+        } else {
+            // The loss derivatives carry 1 / B and whatever the value error is: no fixed scale keeps them
+            // inside f16's range.  The tile is scaled by a power of two (exact) that puts the wave's largest
+            // |dz2| into [2^14, 2^15), and the products are scaled back where (1 - h1^2) is applied.
+            float mx = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(dz2[o][r]), __builtin_fabsf(dz2[o][r + 1])));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
+            int E = (int)(__builtin_bit_cast(uint32_t, mx) >> 23);          // biased exponent of the wave's maximum
+            E = E < 16 ? 16 : (E > 254 ? 254 : E);
+            const float up = __builtin_bit_cast(float, (uint32_t)(268 - E) << 23);     // 2^(14 - e)
+            const float down = __builtin_bit_cast(float, (uint32_t)(E - 14) << 23);    // 2^(e - 14)
+            f32x16 dzs[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) dzs[o] = dz2[o] * up;
+            Frag16 bh[4], bl[4];
+            split_tile(dzs, bh, bl);
+            chain16(lds + OFF_F2T, lane, bh, bl, dz1);
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float h = h1[o][r];
+                    dz1[o][r] = dz1[o][r] * (down * (1.0f - h * h));
+                }
+        }
 
         // ---- dW1 (and db1 in column OBS) += dz1 [x, 1]^T
 #pragma unroll
@@ -537,7 +636,7 @@ inline int upd_blocks(long B)
 }
 
 template <int OBS, int A, bool DO_P, bool DO_V>
-int launch_update(UpdArgs a, float *grads, float *out5, void *workspace, size_t workspace_bytes, hipStream_t s)
+int launch_update(UpdArgs a, int net_mode, float *grads, float *out5, void *workspace, size_t workspace_bytes, hipStream_t s)
 {
     using L = GradLayout<OBS, A, DO_P, DO_V>;
     const int blocks = upd_blocks(a.B), nwaves = blocks * (UPD_BLOCK / 64);
@@ -546,7 +645,8 @@ int launch_update(UpdArgs a, float *grads, float *out5, void *workspace, size_t 
     PPO_REQUIRE(workspace_bytes >= part_bytes + (size_t)nwaves * NSCAL * sizeof(double));
     a.partials = static_cast<float *>(workspace);
     a.scal = reinterpret_cast<double *>(static_cast<char *>(workspace) + part_bytes);
-    hipLaunchKernelGGL((k_update<OBS, A, DO_P, DO_V>), dim3(blocks), dim3(UPD_BLOCK), 0, s, a);
+    if (net_mode == PPO_NET_F16_SPLIT) hipLaunchKernelGGL((k_update<OBS, A, DO_P, DO_V, true>), dim3(blocks), dim3(UPD_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k_update<OBS, A, DO_P, DO_V, false>), dim3(blocks), dim3(UPD_BLOCK), 0, s, a);
     int rc = ppo_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(k_update_reduce, dim3((L::P + 63) / 64), dim3(64 * RED_GROUPS), 0, s, a.partials, a.scal, blocks, nwaves, L::P, a.B,
@@ -572,7 +672,7 @@ size_t ppo_dense_update_grad_floats(int obs_dim, int num_actions, int heads)
     return (size_t)(H * obs_dim + H + H * H + H + (p ? num_actions * H + num_actions : 0) + (v ? H + 1 : 0));
 }
 
-int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float *w1, const float *b1, const float *w2,
+int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, int net_mode, const float *w1, const float *b1, const float *w2,
                            const float *b2, const float *policy_w, const float *policy_b, const float *critic_w,
                            const float *critic_b, const long *idx, const float *states, const int *actions, const float *old_lp,
                            const float *old_v, const float *adv, const double *stats3, double clip, int norm_adv,
@@ -581,6 +681,7 @@ int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float 
 {
     PPO_REQUIRE((obs_dim == 4 || obs_dim == 6) && (num_actions == 2 || num_actions == 3));
     PPO_REQUIRE(heads >= 1 && heads <= 3 && B >= 1);
+    PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT);
     const bool do_p = heads & 1, do_v = heads & 2;
     PPO_REQUIRE(w1 && b1 && w2 && b2 && states && old_v && adv && out5 && grads && workspace);
     PPO_REQUIRE(!do_p || (policy_w && policy_b && actions && old_lp));
@@ -597,9 +698,9 @@ int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, const float 
     hipStream_t s = (hipStream_t)stream;
 #define UPD_CASE(OBS_, A_)                                                                                             \
     if (obs_dim == OBS_ && num_actions == A_) {                                                                        \
-        if (do_p && do_v) return launch_update<OBS_, A_, true, true>(a, grads, out5, workspace, workspace_bytes, s);   \
-        if (do_p) return launch_update<OBS_, A_, true, false>(a, grads, out5, workspace, workspace_bytes, s);          \
-        return launch_update<OBS_, A_, false, true>(a, grads, out5, workspace, workspace_bytes, s);                    \
+        if (do_p && do_v) return launch_update<OBS_, A_, true, true>(a, net_mode, grads, out5, workspace, workspace_bytes, s);   \
+        if (do_p) return launch_update<OBS_, A_, true, false>(a, net_mode, grads, out5, workspace, workspace_bytes, s);          \
+        return launch_update<OBS_, A_, false, true>(a, net_mode, grads, out5, workspace, workspace_bytes, s);                    \
     }
     UPD_CASE(4, 2) UPD_CASE(4, 3) UPD_CASE(6, 2) UPD_CASE(6, 3)
 #undef UPD_CASE

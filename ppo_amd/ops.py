@@ -430,15 +430,17 @@ def dense_update_supported(agent) -> bool:
 
 
 def dense_update_grads(agent, states, actions, old_log_probs, old_values, advantages, clip_ratio, norm_adv, clip_va_loss,
-                       c_pi, c_v, c_ent, stats3=None, idx=None):
+                       c_pi, c_v, c_ent, stats3=None, idx=None, net_mode: int = NET_F32):
     """ppo_dense_update_grads for a ppo_amd Agent: one launch per backbone.
     Returns (out5, groups): out5 = device f32[5] {policy_loss, value_loss, clip_frac, kl_div, entropy};
     groups = one list of (parameter, gradient tensor) per launch -- [all parameters] for a joint network,
     [policy backbone + policy head, value backbone + critic head] for split networks -- the gradients being
     views of one flat buffer per launch.  Gradient of  c_pi policy_loss + c_v value_loss - c_ent entropy.
     idx (int64 [B], optional): the minibatch is rows idx of the given (flattened rollout) tensors -- the kernel
-    gathers as it goes (reference src/ppo.py:582-588); the advantage statistics are those of the minibatch."""
+    gathers as it goes (reference src/ppo.py:582-588); the advantage statistics are those of the minibatch.
+    net_mode: NET_F32, or NET_F16_SPLIT for parameter sets inside the split mode's limits (split_ok)."""
     lib = _lib.load()
+    assert net_mode in (NET_F32, NET_F16_SPLIT)
     dev = states.device
     rows = int(states.shape[0])
     B = rows if idx is None else int(idx.numel())
@@ -468,7 +470,7 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
         for p in params:
             assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
         rc = lib.ppo_dense_update_grads(
-            obs, A, heads, l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(),
+            obs, A, heads, int(net_mode), l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(),
             _ptr(pw), _ptr(pb), _ptr(cw), _ptr(cb), _ptr(idx), states.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr(),
             old_values.data_ptr(), advantages.data_ptr(), _ptr(stats3), float(clip_ratio), int(bool(norm_adv)),
             int(bool(clip_va_loss)), B, float(c_pi), float(c_v), float(c_ent), out5.data_ptr(), g.data_ptr(),

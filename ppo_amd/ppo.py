@@ -696,6 +696,9 @@ class PPO:
         # dense 64-64 tanh Agent + Discrete head: forward, loss, backward and weight gradients of a minibatch in
         # one kernel (ppo_dense_update_grads) instead of the PyTorch MLP around the loss kernel
         fused_update = (self.fused_dense_update and fused_head and fused_gather and ops.dense_update_supported(self.agent))
+        # its 64 x 64 products in the arithmetic the rollout just ran with: the split kernels inside the limits
+        # checked when the parameters were packed (ops.split_ok), exact f32 products otherwise
+        upd_mode = ops.NET_F16_SPLIT if ve.net_mode_used == ops.NET_F16_SPLIT else ops.NET_F32
         self.last_paths = {"fused_head": bool(fused_head), "fused_gather": bool(fused_gather),
                            "fused_update": bool(fused_update)}
         for _epoch in range(num_epochs):
@@ -719,7 +722,7 @@ class PPO:
                     out5, groups = ops.dense_update_grads(
                         self.agent, states, actions, log_probs, values, advantages, clip_ratio, self.norm_adv,
                         self.clip_va_loss, c_pi=lr_anneal, c_v=critic_coef * lr_anneal, c_ent=entropy_coef * lr_anneal,
-                        stats3=stats3, idx=idx)
+                        stats3=stats3, idx=idx, net_mode=upd_mode)
                     policy_loss, critic_loss, clip_frac, kl_div, entropy = out5.unbind(0)
                 elif fused_head:   # Categorical log-prob + entropy + ratio + losses in one pass (:186-216, :595-599)
                     logits, new_values = self.agent.policy_and_values(mb_states)

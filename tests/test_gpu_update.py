@@ -49,10 +49,14 @@ def _autograd(agent, mb, clip, norm_adv, clip_va, c_pi, c_v, c_ent, dtype):
     return [float(pl), float(vl), float(cf), float(kl), float(entropy)], grads
 
 
+MODES = pytest.mark.parametrize("net_mode", [0, 1], ids=["f32", "f16split"])   # PPO_NET_F32, PPO_NET_F16_SPLIT
+
+
+@MODES
 @pytest.mark.parametrize("B", [1, 31, 32, 33, 1000, 262144 + 17])
 @pytest.mark.parametrize("joint", [1, 0], ids=["joint", "split"])
 @pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
-def test_fused_update_matches_autograd(kind, joint, B):
+def test_fused_update_matches_autograd(kind, joint, B, net_mode):
     from ppo_amd import Agent, ops
     from ppo_amd.envs import DeviceEnv
     gen = torch.Generator(device="cuda").manual_seed(B * 7 + joint)
@@ -68,7 +72,7 @@ def test_fused_update_matches_autograd(kind, joint, B):
         if B == 1 and norm_adv:
             continue                                    # std of one sample is NaN in the reference too
         assert ops.dense_update_supported(agent)
-        out5, groups = ops.dense_update_grads(agent, *mb[:5], clip, norm_adv, clip_va, c_pi, c_v, c_ent)
+        out5, groups = ops.dense_update_grads(agent, *mb[:5], clip, norm_adv, clip_va, c_pi, c_v, c_ent, net_mode=net_mode)
         assert len(groups) == (1 if joint else 2)
         pairs = [pg for grp in groups for pg in grp]
         want64, g64 = _autograd(agent, mb, clip, norm_adv, clip_va, c_pi, c_v, c_ent, torch.float64)
@@ -85,11 +89,12 @@ def test_fused_update_matches_autograd(kind, joint, B):
             ref, t32 = g64[n], g32[n].double()
             err = float((g.double() - ref).abs().max())
             bar = 4.0 * float((t32 - ref).abs().max()) + 2e-6 * float(ref.abs().max()) + 1e-12
-            assert err <= bar, (kind, joint, B, norm_adv, n, err, bar)
+            assert err <= bar, (kind, joint, B, norm_adv, net_mode, n, err, bar)
         assert seen == set(g64.keys())                  # every parameter with a gradient got one, and no other
 
 
-def test_fused_update_at_the_bench_minibatch_size():
+@MODES
+def test_fused_update_at_the_bench_minibatch_size(net_mode):
     """B = 2 097 152 (BASELINE configs[1]: T N / 4), joint CartPole network, gathered through idx from the 8 M rows of
     a rollout: same bars as above."""
     from ppo_amd import Agent, ops
@@ -101,7 +106,7 @@ def test_fused_update_at_the_bench_minibatch_size():
     rows, B = 128 * 65536, 2097152
     full = _minibatch("cartpole", rows, gen)
     idx = torch.randperm(rows, device="cuda", generator=gen)[:B].contiguous()
-    out5, groups = ops.dense_update_grads(agent, *full[:5], 0.2, 1, 1, 1.0, 0.5, 0.01, idx=idx)
+    out5, groups = ops.dense_update_grads(agent, *full[:5], 0.2, 1, 1, 1.0, 0.5, 0.01, idx=idx, net_mode=net_mode)
     mb = tuple(t[idx].contiguous() for t in full[:5]) + (2,)
     want64, g64 = _autograd(agent, mb, 0.2, 1, 1, 1.0, 0.5, 0.01, torch.float64)
     _, g32 = _autograd(agent, mb, 0.2, 1, 1, 1.0, 0.5, 0.01, torch.float32)
@@ -115,7 +120,8 @@ def test_fused_update_at_the_bench_minibatch_size():
         assert err <= bar, (names[id(p)], err, bar)
 
 
-def test_fused_update_gathers_its_minibatch():
+@MODES
+def test_fused_update_gathers_its_minibatch(net_mode):
     """idx given: the minibatch is rows idx of the flattened rollout tensors (reference src/ppo.py:582-588); same
     result, bit for bit, as the gathered minibatch handed over directly."""
     from ppo_amd import Agent, ops
@@ -127,24 +133,25 @@ def test_fused_update_gathers_its_minibatch():
         rows, B = 300000, 70001
         full = _minibatch(kind, rows, gen)
         idx = torch.randperm(rows, device="cuda", generator=gen)[:B].contiguous()
-        a5, a = ops.dense_update_grads(agent, *full[:5], 0.2, 1, 1, 1.0, 0.5, 0.01, idx=idx)
+        a5, a = ops.dense_update_grads(agent, *full[:5], 0.2, 1, 1, 1.0, 0.5, 0.01, idx=idx, net_mode=net_mode)
         mb = [t[idx].contiguous() for t in full[:5]]
-        b5, b = ops.dense_update_grads(agent, *mb, 0.2, 1, 1, 1.0, 0.5, 0.01)
+        b5, b = ops.dense_update_grads(agent, *mb, 0.2, 1, 1, 1.0, 0.5, 0.01, net_mode=net_mode)
         assert torch.equal(a5, b5)
         for ga, gb in zip(a, b):
             for (_, x), (_, y) in zip(ga, gb):
                 assert torch.equal(x, y)
 
 
-def test_fused_update_is_deterministic_and_masks_the_tail():
+@MODES
+def test_fused_update_is_deterministic_and_masks_the_tail(net_mode):
     from ppo_amd import Agent, ops
     from ppo_amd.envs import DeviceEnv
     gen = torch.Generator(device="cuda").manual_seed(5)
     probe = DeviceEnv("cartpole")
     agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
     mb = _minibatch("cartpole", 100003, gen)
-    a5, a = ops.dense_update_grads(agent, *mb[:5], 0.2, 1, 1, 1.0, 0.5, 0.01)
-    b5, b = ops.dense_update_grads(agent, *mb[:5], 0.2, 1, 1, 1.0, 0.5, 0.01)
+    a5, a = ops.dense_update_grads(agent, *mb[:5], 0.2, 1, 1, 1.0, 0.5, 0.01, net_mode=net_mode)
+    b5, b = ops.dense_update_grads(agent, *mb[:5], 0.2, 1, 1, 1.0, 0.5, 0.01, net_mode=net_mode)
     assert torch.equal(a5, b5)
     for (_, ga), (_, gb) in zip(a[0], b[0]):
         assert torch.equal(ga, gb)
@@ -200,17 +207,46 @@ def test_fused_update_rejects_what_it_does_not_cover():
     g = torch.empty(lib.ppo_dense_update_grad_floats(4, 2, 3), dtype=torch.float32, device="cuda")
     out5 = torch.zeros(5, device="cuda")
     l1, l2 = agent.pi_backbone[0], agent.pi_backbone[2]
-    def call(obs=4, A=2, heads=3, B=4096, ws_bytes=None, policy_w=agent.policy.weight.data_ptr()):
+    def call(obs=4, A=2, heads=3, B=4096, ws_bytes=None, policy_w=agent.policy.weight.data_ptr(), mode=0):
         return lib.ppo_dense_update_grads(
-            obs, A, heads, l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(), policy_w,
+            obs, A, heads, mode, l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(), policy_w,
             agent.policy.bias.data_ptr(), agent.critic.weight.data_ptr(), agent.critic.bias.data_ptr(), None,
             mb[0].data_ptr(), mb[1].data_ptr(), mb[2].data_ptr(), mb[3].data_ptr(), mb[4].data_ptr(), None, 0.2, 0, 1, B,
             1.0, 0.5, 0.01, out5.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel() if ws_bytes is None else ws_bytes, None)
-    assert call() == 0
-    for bad in (dict(obs=5), dict(A=4), dict(heads=0), dict(heads=4), dict(B=0), dict(ws_bytes=1024), dict(policy_w=None)):
+    assert call() == 0 and call(mode=1) == 0
+    for bad in (dict(obs=5), dict(A=4), dict(heads=0), dict(heads=4), dict(B=0), dict(ws_bytes=1024), dict(policy_w=None), dict(mode=2)):
         assert call(**bad) == 1, bad
     torch.cuda.synchronize()
     actions = mb[1].clone()
     actions[17] = 2                                                     # CartPole has actions 0 and 1
     out, groups = ops.dense_update_grads(agent, mb[0], actions, mb[2], mb[3], mb[4], 0.2, 0, 1, 1.0, 0.5, 0.01)
     assert torch.isnan(out[0]) and any(torch.isnan(gr).any() for _, gr in groups[0])
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1.0, 1e6], ids=["tiny", "unit", "huge"])
+def test_split_mode_scales_the_loss_derivatives_per_tile(scale):
+    """PPO_NET_F16_SPLIT scales dz2 per 32-sample tile by a power of two before it becomes an f16 operand: value
+    errors (and so loss derivatives) 1e6 times smaller / larger than usual, and a minibatch that mixes both, leave
+    the gradients at the same relative distance from float64 autograd."""
+    from ppo_amd import Agent, ops
+    from ppo_amd.envs import DeviceEnv
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    torch.manual_seed(77)
+    probe = DeviceEnv("cartpole")
+    agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=1, device="cuda")
+    B = 50000
+    states, actions, old_lp, old_v, adv, A = _minibatch("cartpole", B, gen)
+    old_v = old_v * scale
+    adv = adv * scale
+    old_v[::7] *= 1e-3                                   # tiles that mix magnitudes
+    mb = (states, actions, old_lp, old_v, adv, A)
+    out5, groups = ops.dense_update_grads(agent, *mb[:5], 0.2, 0, 0, 1.0, 0.5, 0.01, net_mode=1)
+    _, g64 = _autograd(agent, mb, 0.2, 0, 0, 1.0, 0.5, 0.01, torch.float64)
+    _, g32 = _autograd(agent, mb, 0.2, 0, 0, 1.0, 0.5, 0.01, torch.float32)
+    names = {id(p): n for n, p in agent.named_parameters()}
+    for p, g in groups[0]:
+        ref, t32 = g64[names[id(p)]], g32[names[id(p)]].double()
+        assert bool(torch.isfinite(g).all())
+        err = float((g.double() - ref).abs().max())
+        bar = 4.0 * float((t32 - ref).abs().max()) + 2e-6 * float(ref.abs().max()) + 1e-12
+        assert err <= bar, (names[id(p)], scale, err, bar)

@@ -33,8 +33,8 @@ def timed(fn, reps=10):
 for joint in (1, 0):
     agent = Agent(probe.observation_space, probe.action_space, conv_net=0, joint_net=joint, device="cuda")
 
-    def fused():
-        ops.dense_update_grads(agent, states, actions, old_lp, old_v, adv, 0.2, 1, 1, 1.0, 0.5, 0.01)
+    def fused(mode=ops.NET_F32):
+        ops.dense_update_grads(agent, states, actions, old_lp, old_v, adv, 0.2, 1, 1, 1.0, 0.5, 0.01, net_mode=mode)
 
     def torch_path():
         for p in agent.parameters():
@@ -47,5 +47,6 @@ for joint in (1, 0):
             (pl - 0.01 * ent).backward(retain_graph=True)
             (0.5 * vl).backward()
 
-    tf, tt = timed(fused), timed(torch_path)
-    print(f"{kind} {'joint' if joint else 'split'} B={B}: fused {tf:.3f} ms   PyTorch + loss/wgrad kernels {tt:.3f} ms   ({tt / tf:.1f}x)")
+    tf, ts, tt = timed(fused), timed(lambda: fused(ops.NET_F16_SPLIT)), timed(torch_path)
+    print(f"{kind} {'joint' if joint else 'split'} B={B}: fused {tf:.3f} ms (f32 products)  {ts:.3f} ms (f16-split 64 x 64 products)   "
+          f"PyTorch + loss/wgrad kernels {tt:.3f} ms   ({tt / ts:.1f}x)")
