@@ -29,6 +29,7 @@
 // one row per workgroup goes to the workspace, and k_update_reduce adds the rows in a fixed order in
 // f64 (deterministic) and finishes the loss scalars.  The minibatch is gathered on the fly: a sample's
 // inputs are fetched through idx one tile ahead of their use.
+#include <type_traits>
 #include "common.h"
 #include "loss_core.h"
 #include "net_layout.h"
@@ -105,6 +106,25 @@ __device__ __forceinline__ float sum_halves(float x)
     return a + b;
 }
 
+// max over the wave of the bit patterns of non-negative floats (they order like the floats), as a wave-uniform
+// value: DPP steps inside each row of 16 lanes (no LDS round trips, unlike __shfl_xor), then the four rows through
+// v_readlane
+__device__ __forceinline__ uint32_t wave_max_bits(uint32_t v)
+{
+    const auto step = [](uint32_t x, auto ctrl) {
+        const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, 0xF, 0xF, true);
+        return x > y ? x : y;
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1, 0, 3, 2]
+    v = step(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2, 3, 0, 1]
+    v = step(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});    // row_mirror
+    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
 // f16-split form of a register-chained 64 x 64 layer (F16 = true): the 32 registers a lane holds of a
 // [64 units][32 samples] tile -> the four k-steps' B operands, high and low pieces
 __device__ __forceinline__ void split_tile(const f32x16 (&v)[2], Frag16 (&bh)[4], Frag16 (&bl)[4])
@@ -147,8 +167,13 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
     // end, over everything else): weight fragments shared by the block, then the per-wave staging tiles
     constexpr int NW = UPD_BLOCK / 64;
     constexpr int OFF_F1 = 0, OFF_F2 = OFF_F1 + S1 * 128, OFF_F2T = OFF_F2 + 33 * 128, OFF_HW = OFF_F2T + 32 * 128;
-    constexpr int OFF_HB = OFF_HW + NHEAD * H, OFF_SA = OFF_HB + 4, OFF_SB = OFF_SA + NW * H * SPAD;
-    constexpr int OFF_SX = OFF_SB + NW * H * SPAD, LDS_FLOATS = OFF_SX + NW * 8 * SPAD;
+    // per-wave staging: two f32 tiles [unit 64][sample 32 + 1]; the f16 form lays four tiles of packed piece pairs
+    // ([unit pair 32][sample 32 + 4]: dz2 high / low, h1 high / low) over the same words
+    constexpr int PROW = 36, PTILE = 32 * PROW;
+    constexpr int STG_WAVE = F16 ? 4 * PTILE : 2 * H * SPAD;
+    static_assert(STG_WAVE >= 2 * H * SPAD && STG_WAVE % 4 == 0, "the f32 staging tiles live in the same words");
+    constexpr int OFF_HB = OFF_HW + NHEAD * H, OFF_SA = OFF_HB + 4;
+    constexpr int OFF_SX = OFF_SA + NW * STG_WAVE, LDS_FLOATS = OFF_SX + NW * 8 * SPAD;
     static_assert(LDS_FLOATS >= NW * L::P, "the waves' gradient rows must fit for the final addition");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float(*F1)[2][64] = reinterpret_cast<float(*)[2][64]>(lds + OFF_F1);     // layer 1, A operand: [k-step][row tile][lane]
@@ -156,8 +181,6 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
     float(*F2T)[2][64] = reinterpret_cast<float(*)[2][64]>(lds + OFF_F2T);   // layer 2 transposed (dh1 = W2^T dz2)
     float(*HW)[H] = reinterpret_cast<float(*)[H]>(lds + OFF_HW);             // head rows, natural order
     float *hbias = lds + OFF_HB;
-    float(*SA)[H][SPAD] = reinterpret_cast<float(*)[H][SPAD]>(lds + OFF_SA);   // staging: [wave][unit][sample]
-    float(*SB)[H][SPAD] = reinterpret_cast<float(*)[H][SPAD]>(lds + OFF_SB);
     float(*SX)[8][SPAD] = reinterpret_cast<float(*)[8][SPAD]>(lds + OFF_SX);   // inputs (+ a row of ones at OBS) / head derivatives
     const Net &n = a.net;
     for (int k = threadIdx.x; k < S1 * 128; k += UPD_BLOCK) {
@@ -221,8 +244,33 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 
     const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31, wv = threadIdx.x >> 6;
     const float one = half == 0 ? 1.0f : 0.0f;
-    float(*sa)[SPAD] = SA[wv];
-    float(*sb)[SPAD] = SB[wv];
+    float *stage = lds + OFF_SA + wv * STG_WAVE;
+    float(*sa)[SPAD] = reinterpret_cast<float(*)[SPAD]>(stage);               // staging: [unit][sample]
+    float(*sb)[SPAD] = reinterpret_cast<float(*)[SPAD]>(stage + H * SPAD);
+    uint32_t *pst = reinterpret_cast<uint32_t *>(stage);                      // f16 form: tiles 0 / 1 dz2 high / low, 2 / 3 h1 high / low
+    const uint32_t psel = (lane & 1) ? 0x07060302u : 0x05040100u;              // v_perm: the odd / even unit's half of two staged words
+    // k-steps' pieces (a lane's registers of a [64 units][32 samples] tile, two adjacent units per word) -> staging tile
+    const auto put_pieces = [&](int tile, const Frag16 (&b)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = j >> 1, r = 8 * (j & 1) + 2 * q;
+                pst[tile * PTILE + (unit(o, r, 0) / 2 + 2 * half) * PROW + col] = b[j].w[q];
+            }
+    };
+    // MFMA operand with the samples as k: row (or column) = unit 32 t + (lane & 31), elements = samples 16 m + 8 half + 0..7
+    const auto get_pieces = [&](int tile, int t, int m) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(pst + tile * PTILE + (16 * t + (col >> 1)) * PROW + 16 * m + 8 * half);
+        const uint4 x = src[0], y = src[1];
+        Frag16 f;
+        f.w[0] = __builtin_amdgcn_perm(x.y, x.x, psel);
+        f.w[1] = __builtin_amdgcn_perm(x.w, x.z, psel);
+        f.w[2] = __builtin_amdgcn_perm(y.y, y.x, psel);
+        f.w[3] = __builtin_amdgcn_perm(y.w, y.z, psel);
+        return f;
+    };
+    int Ecur = 0, Emax = 0;                        // f16 form: biased exponent the dW2 accumulators are scaled for (0: nothing yet)
     float(*sx)[SPAD] = SX[wv];
     const LossConsts c = loss_consts(a.stats3, a.norm_adv, a.clip_va, a.lo, a.hi, a.epsf, a.B);
 
@@ -308,6 +356,8 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
         } else {
             Frag16 bh[4], bl[4];
             split_tile(h1, bh, bl);
+            put_pieces(2, bh);                          // for dW2 below: the previous tile is done with these words
+            put_pieces(3, bl);
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -411,29 +461,28 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
                 }
             }
 
-        // ---- dW2 += dz2 h1^T: transpose both through the staging tiles, samples become the k dimension
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sa[unit(o, r, half)][col] = dz2[o][r];
-                sb[unit(o, r, half)][col] = h1[o][r];
-            }
-        __builtin_amdgcn_wave_barrier();               // (compiler ordering only: a wave's LDS operations execute in order)
-#pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-            const int s = 2 * j + half;
-            const float a0 = sa[col][s], a1 = sa[32 + col][s], b0 = sb[col][s], b1 = sb[32 + col][s];
-            gW2[0][0] = UPD_MFMA(a0, b0, gW2[0][0]);
-            gW2[0][1] = UPD_MFMA(a0, b1, gW2[0][1]);
-            gW2[1][0] = UPD_MFMA(a1, b0, gW2[1][0]);
-            gW2[1][1] = UPD_MFMA(a1, b1, gW2[1][1]);
-        }
-
-        __builtin_amdgcn_wave_barrier();
-        // ---- dh1 = W2^T dz2 (register-chained), dz1 = dh1 (1 - h1^2)
         f32x16 dz1[2] = {zero16(), zero16()};
         if constexpr (!F16) {
+            // ---- dW2 += dz2 h1^T: transpose both through the staging tiles, samples become the k dimension
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sa[unit(o, r, half)][col] = dz2[o][r];
+                    sb[unit(o, r, half)][col] = h1[o][r];
+                }
+            __builtin_amdgcn_wave_barrier();           // (compiler ordering only: a wave's LDS operations execute in order)
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int s = 2 * j + half;
+                const float a0 = sa[col][s], a1 = sa[32 + col][s], b0 = sb[col][s], b1 = sb[32 + col][s];
+                gW2[0][0] = UPD_MFMA(a0, b0, gW2[0][0]);
+                gW2[0][1] = UPD_MFMA(a0, b1, gW2[0][1]);
+                gW2[1][0] = UPD_MFMA(a1, b0, gW2[1][0]);
+                gW2[1][1] = UPD_MFMA(a1, b1, gW2[1][1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- dh1 = W2^T dz2 (register-chained), dz1 = dh1 (1 - h1^2)
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
 #pragma unroll
@@ -447,25 +496,71 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
                     dz1[o][r] = dz1[o][r] * (1.0f - h * h);
                 }
         } else {
-            // The loss derivatives carry 1 / B and whatever the value error is: no fixed scale keeps them
-            // inside f16's range.  The tile is scaled by a power of two (exact) that puts the wave's largest
-            // |dz2| into [2^14, 2^15), and the products are scaled back where (1 - h1^2) is applied.
+            // The loss derivatives carry 1 / B and whatever the value error is: no fixed scale keeps dz2 inside
+            // f16's range.  dz2 is scaled by a power of two (exact) before it is split: 2^(14 - e), e the exponent
+            // of the largest |dz2| of a tile.  The dW2 accumulators live in that scale across tiles, so it is kept
+            // while a tile's maximum lands in [2^-6, 2^15) (anything smaller still has the absolute accuracy of the
+            // tiles that set the scale); when it must change, the accumulators are rescaled (exact; rare: the wave's
+            // maximum moved by a binade upwards or by 2^20 downwards).  Never more than 2^60 below the largest tile
+            // seen: the accumulators stay far from f32's range.  The epilogue scales them back.
             float mx = 0.0f;
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(dz2[o][r]), __builtin_fabsf(dz2[o][r + 1])));
+            const uint32_t mxb = wave_max_bits(__builtin_bit_cast(uint32_t, mx));   // in SGPRs: what follows is scalar code
+            if (mxb != 0u) {
+                int E = (int)(mxb >> 23);                                       // biased exponent of the wave's maximum
+                E = E < 16 ? 16 : (E > 254 ? 254 : E);
+                Emax = E > Emax ? E : Emax;
+                int En = Ecur;
+                if (E > Ecur) En = E;
+                else if (E < Ecur - 20) En = E > Emax - 60 ? E : Emax - 60;
+                if (En != Ecur) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
-            int E = (int)(__builtin_bit_cast(uint32_t, mx) >> 23);          // biased exponent of the wave's maximum
-            E = E < 16 ? 16 : (E > 254 ? 254 : E);
-            const float up = __builtin_bit_cast(float, (uint32_t)(268 - E) << 23);     // 2^(14 - e)
-            const float down = __builtin_bit_cast(float, (uint32_t)(E - 14) << 23);    // 2^(e - 14)
+                    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                        for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) gW2[ut][vt][r] = __builtin_ldexpf(gW2[ut][vt][r], Ecur - En);
+                    Ecur = En;
+                }
+            }
+            const int Eu = Ecur < 16 ? 16 : Ecur;
+            const float up = __builtin_bit_cast(float, (uint32_t)(268 - Eu) << 23);     // 2^(14 - e)
+            const float down = __builtin_bit_cast(float, (uint32_t)(Eu - 14) << 23);    // 2^(e - 14)
             f32x16 dzs[2];
 #pragma unroll
             for (int o = 0; o < 2; ++o) dzs[o] = dz2[o] * up;
             Frag16 bh[4], bl[4];
             split_tile(dzs, bh, bl);
+            // ---- dW2 += dz2 h1^T with the samples as k: the pieces go through the staging tiles, two units per word
+            put_pieces(0, bh);
+            put_pieces(1, bl);
+            __builtin_amdgcn_wave_barrier();           // (compiler ordering only: a wave's LDS operations execute in order)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                Frag16 ah[2], al[2], hh[2], hl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ah[t] = get_pieces(0, t, m); al[t] = get_pieces(1, t, m);
+                    hh[t] = get_pieces(2, t, m); hl[t] = get_pieces(3, t, m);
+                }
+#pragma unroll
+                for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                    for (int vt = 0; vt < 2; ++vt) gW2[ut][vt] = mfma16(ah[ut], hl[vt], gW2[ut][vt]);
+#pragma unroll
+                for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                    for (int vt = 0; vt < 2; ++vt) gW2[ut][vt] = mfma16(al[ut], hh[vt], gW2[ut][vt]);
+#pragma unroll
+                for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                    for (int vt = 0; vt < 2; ++vt) gW2[ut][vt] = mfma16(ah[ut], hh[vt], gW2[ut][vt]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- dh1 = W2^T dz2 (register-chained, the same pieces), dz1 = dh1 (1 - h1^2)
             chain16(lds + OFF_F2T, lane, bh, bl, dz1);
 #pragma unroll
             for (int o = 0; o < 2; ++o)
@@ -525,7 +620,7 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
         for (int r = 0; r < 16; ++r) {
             const int u = unit(ut, r, half);
 #pragma unroll
-            for (int vt = 0; vt < 2; ++vt) g[L::W2 + u * H + 32 * vt + col] = gW2[ut][vt][r];
+            for (int vt = 0; vt < 2; ++vt) g[L::W2 + u * H + 32 * vt + col] = F16 ? __builtin_ldexpf(gW2[ut][vt][r], Ecur - 141) : gW2[ut][vt][r];
         }
     {
         const int c16 = lane & 15, g16 = lane >> 4;
