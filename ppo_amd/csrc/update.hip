@@ -98,6 +98,19 @@ __device__ __forceinline__ float fast_tanh(float x)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
 }
 
+// two at a time: the multiply, the add and the fma as packed-f32 instructions (one issue slot for two values);
+// same operations, same results
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 fast_tanh2(f32x2 x)
+{
+    const f32x2 y = x * 2.8853900817779268f;
+    f32x2 e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+    e += 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
+}
+__device__ __forceinline__ f32x2 one_minus_sq(f32x2 h) { return __builtin_elementwise_fma(-h, h, f32x2{1.0f, 1.0f}); }   // tanh'
+
 // sum of x over the lane and its partner in the other half (lane ^ 32), in both
 __device__ __forceinline__ float sum_halves(float x)
 {
@@ -279,12 +292,12 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 gW1[4] = {zero4, zero4, zero4, zero4};                       // [16-row tile: h1 unit], cols: input i (OBS = bias)
     f32x4 gWh[4] = {zero4, zero4, zero4, zero4};                       // rows: head j, [16-col tile: h2 unit]
-    float gb2[2][16];                                                  // column sums of dz2, this lane's samples
+    f32x2 gb2[2][8];                                                   // column sums of dz2, this lane's samples (register pairs)
     float gbh[NHEAD] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gb2[o][r] = 0.0f;
+        for (int r = 0; r < 8; ++r) gb2[o][r] = f32x2{0.0f, 0.0f};
     double acc[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0};
 
     const long tiles = (a.B + 31) / 32;
@@ -344,7 +357,10 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h1[o][r] = fast_tanh(h1[o][r]);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = fast_tanh2(f32x2{h1[o][r], h1[o][r + 1]});
+                h1[o][r] = t[0]; h1[o][r + 1] = t[1];
+            }
         if constexpr (!F16) {
 #pragma unroll
             for (int o = 0; o < 2; ++o) h2[o] = UPD_MFMA(F2[0][o][lane], one, zero16());
@@ -374,8 +390,12 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int u0 = unit(o, 4 * r4, 0);             // units 4 r4 .. 4 r4 + 3 of this lane half are adjacent
                 float hv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hv[q] = h2[o][4 * r4 + q] = fast_tanh(h2[o][4 * r4 + q]);
+                {
+                    const f32x2 h01 = fast_tanh2(f32x2{h2[o][4 * r4], h2[o][4 * r4 + 1]});
+                    const f32x2 h23 = fast_tanh2(f32x2{h2[o][4 * r4 + 2], h2[o][4 * r4 + 3]});
+                    hv[0] = h2[o][4 * r4] = h01[0]; hv[1] = h2[o][4 * r4 + 1] = h01[1];
+                    hv[2] = h2[o][4 * r4 + 2] = h23[0]; hv[3] = h2[o][4 * r4 + 3] = h23[1];
+                }
 #pragma unroll
                 for (int j = 0; j < NHEAD; ++j) {
                     if ((DO_P && j < A) || (DO_V && j == 3)) {
@@ -441,23 +461,22 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int u0 = unit(o, 4 * r4, 0) + 4 * half;
-                float d[4] = {0.f, 0.f, 0.f, 0.f};
+                f32x2 d[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
 #pragma unroll
                 for (int j = 0; j < NHEAD; ++j) {
                     if ((DO_P && j < A) || (DO_V && j == 3)) {
                         const float4 w = *reinterpret_cast<const float4 *>(&HW[j][u0]);
-                        d[0] = __builtin_fmaf(w.x, dout[j], d[0]);
-                        d[1] = __builtin_fmaf(w.y, dout[j], d[1]);
-                        d[2] = __builtin_fmaf(w.z, dout[j], d[2]);
-                        d[3] = __builtin_fmaf(w.w, dout[j], d[3]);
+                        const f32x2 dj = {dout[j], dout[j]};
+                        d[0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, dj, d[0]);
+                        d[1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, dj, d[1]);
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float h = h2[o][4 * r4 + q];
-                    const float z = d[q] * (1.0f - h * h);
-                    dz2[o][4 * r4 + q] = z;
-                    gb2[o][4 * r4 + q] += z;
+                for (int q = 0; q < 2; ++q) {
+                    const int r = 4 * r4 + 2 * q;
+                    const f32x2 z = d[q] * one_minus_sq(f32x2{h2[o][r], h2[o][r + 1]});
+                    dz2[o][r] = z[0]; dz2[o][r + 1] = z[1];
+                    gb2[o][r >> 1] += z;
                 }
             }
 
@@ -491,9 +510,9 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float h = h1[o][r];
-                    dz1[o][r] = dz1[o][r] * (1.0f - h * h);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 z = f32x2{dz1[o][r], dz1[o][r + 1]} * one_minus_sq(f32x2{h1[o][r], h1[o][r + 1]});
+                    dz1[o][r] = z[0]; dz1[o][r + 1] = z[1];
                 }
         } else {
             // The loss derivatives carry 1 / B and whatever the value error is: no fixed scale keeps dz2 inside
@@ -565,9 +584,9 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float h = h1[o][r];
-                    dz1[o][r] = dz1[o][r] * (down * (1.0f - h * h));
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 z = f32x2{dz1[o][r], dz1[o][r + 1]} * (one_minus_sq(f32x2{h1[o][r], h1[o][r + 1]}) * down);
+                    dz1[o][r] = z[0]; dz1[o][r + 1] = z[1];
                 }
         }
 
@@ -649,7 +668,7 @@ __global__ void __launch_bounds__(UPD_BLOCK) k_update(UpdArgs a)
     for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v = gb2[o][r];
+            float v = gb2[o][r >> 1][r & 1];
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
             if (col == 0) g[L::B2 + unit(o, r, half)] = v;
