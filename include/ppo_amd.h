@@ -218,6 +218,20 @@ int ppo_minibatch_gather(const int64_t *idx, long B, long M, const void *states,
                          void *stream);
 
 /*
+ * The epoch's shuffled index list on the device: idx_out [n] i64 = a pseudo-random permutation of
+ * 0 .. n-1.  Replaces `np.random.shuffle(indices)` (src/ppo.py:575-576) -- and torch.randperm, whose
+ * 64-bit key sort costs more than a minibatch step at BASELINE configs[1].  Index i goes through a
+ * keyed bijection of [0, 2^k), 2^k >= n (six xorshift / odd-multiply / add rounds modulo 2^k), applied
+ * again while the result is >= n (cycle walking).  The round keys are Philox4x32-10 words of
+ * (seed; stream_id): a different permutation for every stream_id (the caller counts epochs), the same
+ * one on every device and for every sharding.  Not numpy's generator: no reference stream to match;
+ * tests/test_gpu_shuffle.py checks that it is a permutation, equal to the oracle's restatement bit for
+ * bit, and its statistics (position uniformity, neighbour independence, minibatch composition).
+ * n <= 2^32.
+ */
+int ppo_shuffle_indices(long n, uint64_t seed, uint64_t stream_id, int64_t *idx_out, void *stream);
+
+/*
  * Weight and bias gradient of y = x W^T + b for a small layer (M, K <= 64) over a huge batch:
  * dW[M,K] = sum_b g[b,m] x[b,k], db[M] = sum_b g[b,m] (db may be NULL).  Replaces the weight-gradient
  * GEMMs inside loss.backward() of the update phase (src/ppo.py:606-607, :614-615, :623-624) for the

@@ -157,6 +157,13 @@ def div_by_total_mass_mismatches(n, seed=0, e_lo=-40, e_hi=20):
     return int(f(C.c_long(n), C.c_uint64(seed), C.c_int(e_lo), C.c_int(e_hi)))
 
 
+def shuffle_indices(n, seed, stream_id):
+    """The permutation ppo_shuffle_indices makes (oracle_shuffle_indices), as int64 [n]."""
+    out = np.empty(n, np.int64)
+    lib().oracle_shuffle_indices(C.c_long(n), C.c_uint64(seed), C.c_uint64(stream_id), _p(out, C.c_int64))
+    return out
+
+
 def categorical_check(logits, u, actions, margin=1e-5):
     """Inverse-CDF sampling check in float64: returns (mismatches, ambiguous) -- the number of rows whose
     action differs from the first k with u * sum < cdf_k although u * sum is further than `margin`

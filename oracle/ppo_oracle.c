@@ -565,3 +565,33 @@ void oracle_env_reset_batch(int kind, double *state, int *elapsed, float *ep_ret
         for (int k = 0; k < od; ++k) obs_out[(size_t)n * od + k] = obs[k];
     }
 }
+
+
+/* ---- epoch shuffle (restates ppo_amd/csrc/minibatch.hip: k_shuffle_indices; the reference's
+ * np.random.shuffle(indices), src/ppo.py:575-576, is a different generator -- what is pinned here is that
+ * the device permutation is the function below, that it IS a permutation, and its statistics) ---- */
+void oracle_shuffle_indices(long n, uint64_t seed, uint64_t stream_id, int64_t *out)
+{
+    enum { ROUNDS = 6 };
+    int k = 2;
+    while (k < 32 && (1L << k) < n) ++k;
+    const uint32_t mask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const int sh_a = (k + 1) / 2, sh_b = k / 3 > 1 ? k / 3 : 1;
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x2545F491u};
+    uint32_t w[12];
+    for (uint32_t b = 0; b < 3; ++b) {
+        const uint32_t ctr[4] = {(uint32_t)stream_id, (uint32_t)(stream_id >> 32), b, 0x5348464Cu};
+        oracle_philox4x32_10(ctr, key, w + 4 * b);
+    }
+    for (long i = 0; i < n; ++i) {
+        uint32_t x = (uint32_t)i;
+        do {
+            for (int r = 0; r < ROUNDS; ++r) {
+                x ^= x >> ((r & 1) ? sh_b : sh_a);
+                x = (x * (w[r] | 1u) + w[ROUNDS + r]) & mask;
+            }
+            x ^= x >> sh_a;
+        } while ((long)x >= n);
+        out[i] = (int64_t)x;
+    }
+}

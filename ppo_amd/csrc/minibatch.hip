@@ -8,6 +8,15 @@
 // HBM, latency.  One lane per sample: the 8-byte index load and every store are
 // coalesced; observation / action rows move as one 16-byte access when they are 4 words
 // wide and aligned, word by word otherwise.  Pure data movement: bit-exact by definition.
+//
+// k_shuffle_indices: the permutation itself (reference src/ppo.py:575-576, np.random.shuffle(indices) once
+// per epoch).  torch.randperm sorts 64-bit random keys: eight radix passes over 8.4 M pairs, 0.59 ms per
+// epoch at BASELINE configs[1] -- more than a minibatch step of the update.  Here index i is mapped through
+// a keyed bijection of [0, 2^k), 2^k >= n (xorshift / odd-multiply / add rounds: each step is invertible
+// modulo 2^k, so the whole is), applied again while the result is >= n (cycle walking: still a
+// bijection of [0, n), fewer than two applications on average).  One pass, 8 B written per index, no sort.
+// The keys are Philox4x32-10 words of (seed, stream): integer arithmetic only, the oracle restates it bit
+// for bit (oracle/ppo_oracle.c: oracle_shuffle_indices).
 #include "common.h"
 
 namespace {
@@ -75,6 +84,47 @@ __global__ void __launch_bounds__(MB_BLOCK) k_gather_wide_rows(const int64_t *id
 
 constexpr int WIDE_ROW_WORDS = 32;   // rows at least this wide (and 16-byte granular) take the wide-row kernel
 
+constexpr int SHUF_ROUNDS = 6;
+struct ShuffleKeys {
+    uint32_t mul[SHUF_ROUNDS], add[SHUF_ROUNDS];   // odd multipliers, additive keys
+    uint32_t mask;                                 // 2^k - 1
+    int sh_a, sh_b;                                // the two xorshift distances: ceil(k / 2), max(1, k / 3)
+};
+
+__host__ __device__ inline uint32_t shuffle_bijection(uint32_t x, const ShuffleKeys &q)
+{
+#pragma unroll
+    for (int r = 0; r < SHUF_ROUNDS; ++r) {
+        x ^= x >> ((r & 1) ? q.sh_b : q.sh_a);
+        x = (x * q.mul[r] + q.add[r]) & q.mask;
+    }
+    x ^= x >> q.sh_a;
+    return x;
+}
+
+__global__ void __launch_bounds__(MB_BLOCK) k_shuffle_indices(ShuffleKeys q, long n, int64_t *out)
+{
+    for (long i = (long)blockIdx.x * MB_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * MB_BLOCK) {
+        uint32_t x = (uint32_t)i;
+        do x = shuffle_bijection(x, q);
+        while ((long)x >= n);                      // cycle walking: i < n is on the cycle, so this ends
+        out[i] = (int64_t)x;
+    }
+}
+
+// Philox4x32-10 on the host (common.h has the device form): the round keys are made once per launch
+void host_philox4x32_10(const uint32_t c_in[4], uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    uint32_t c0 = c_in[0], c1 = c_in[1], c2 = c_in[2], c3 = c_in[3];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 }  // namespace
 
 extern "C" {
@@ -119,6 +169,34 @@ int ppo_minibatch_gather(const int64_t *idx, long B, long M, const void *states,
     long blocks = (B + MB_BLOCK - 1) / MB_BLOCK;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_minibatch_gather, dim3((unsigned)blocks), dim3(MB_BLOCK), 0, s, a);
+    return ppo_launch_status();
+}
+
+int ppo_shuffle_indices(long n, uint64_t seed, uint64_t stream_id, int64_t *idx_out, void *stream)
+{
+    PPO_REQUIRE(n >= 0 && n <= (1L << 32));
+    if (n == 0) return 0;
+    PPO_REQUIRE(idx_out && ppo_aligned(idx_out, 8));
+    ShuffleKeys q;
+    int k = 2;
+    while (k < 32 && (1L << k) < n) ++k;
+    q.mask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    q.sh_a = (k + 1) / 2;
+    q.sh_b = k / 3 > 1 ? k / 3 : 1;
+    // key half 1 is offset so that this stream never collides with the reset / sampling streams of the same seed
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ 0x2545F491u;
+    uint32_t w[12];
+    for (uint32_t b = 0; b < 3; ++b) {
+        const uint32_t ctr[4] = {(uint32_t)stream_id, (uint32_t)(stream_id >> 32), b, 0x5348464Cu};
+        host_philox4x32_10(ctr, k0, k1, w + 4 * b);
+    }
+    for (int r = 0; r < SHUF_ROUNDS; ++r) {
+        q.mul[r] = w[r] | 1u;
+        q.add[r] = w[SHUF_ROUNDS + r];
+    }
+    long blocks = (n + MB_BLOCK - 1) / MB_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_shuffle_indices, dim3((unsigned)blocks), dim3(MB_BLOCK), 0, (hipStream_t)stream, q, n, idx_out);
     return ppo_launch_status();
 }
 

@@ -234,6 +234,19 @@ def ppo_losses_discrete(logits, actions, new_v, old_lp, old_v, adv, clip, norm_a
 
 
 # --------------------------------------------------------------------------- minibatch
+def shuffle_indices(n: int, seed: int, stream_id: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """ppo_shuffle_indices: a pseudo-random permutation of 0 .. n-1 as a device int64 tensor, a function of
+    (seed, stream_id) only (reference src/ppo.py:575-576: np.random.shuffle(indices), once per epoch)."""
+    lib = _lib.load()
+    dev = device()
+    if out is None:
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+    assert out.is_cuda and out.dtype == torch.int64 and out.numel() == n and out.is_contiguous()
+    rc = lib.ppo_shuffle_indices(int(n), int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1), _ptr(out), _stream())
+    _lib.check(rc, "ppo_shuffle_indices")
+    return out
+
+
 def minibatch_gather(idx, states, actions, log_probs, values, adv, check_index=False):
     """(states[idx], actions[idx], log_probs[idx], values[idx], adv[idx]) in one launch
     (reference src/ppo.py:582-588).  All inputs are flattened-rollout tensors with M rows."""

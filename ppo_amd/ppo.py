@@ -632,6 +632,10 @@ class PPO:
         # dense Discrete agents (CartPole / Acrobot): the whole minibatch step in one kernel; PPO_AMD_FUSED_UPDATE=0
         # keeps the PyTorch MLP around the loss kernel
         self.fused_dense_update = os.environ.get("PPO_AMD_FUSED_UPDATE", "1") != "0"
+        # the epoch's shuffled index list from ppo_shuffle_indices (one pass; torch.randperm's 64-bit key sort costs
+        # more than a minibatch step at C2 scale); PPO_AMD_SHUFFLE=torch keeps torch.randperm
+        self.device_shuffle = os.environ.get("PPO_AMD_SHUFFLE", "kernel") != "torch"
+        self._shuffle = None         # [seed, epochs shuffled so far]: the permutation is a function of the two
         self.minibatch_hook = None   # tests: called with a dict per minibatch (indices, losses) when set
         self._idle = False           # True while nothing of ours is queued on the device (set by a host read-back)
 
@@ -648,6 +652,18 @@ class PPO:
         the first two carry gradients to prob_ratios / curr_values (ppo_loss_fwd_bwd)."""
         return ops.ppo_losses(prob_ratios, curr_values, None, prev_values, advantages, clip_ratio,
                               self.norm_adv, self.clip_va_loss, ratio_input=True)
+
+    def _epoch_permutation(self, n: int, dev) -> torch.Tensor:
+        """reference src/ppo.py:575-576 (np.random.shuffle(indices)): the rows of this rank's rollout in random order."""
+        if dev.type != "cuda" or not self.device_shuffle:
+            return torch.randperm(n, device=dev)
+        if self._shuffle is None:
+            # an explicit seed, or one drawn from torch's CPU generator (so torch.manual_seed still governs the run)
+            seed = int(self.seed) if self.seed is not None else int(torch.randint(0, 2**62, (1,)).item())
+            self._shuffle = [seed, 0]
+        stream = (ppo_dist.rank() << 40) + self._shuffle[1]          # every rank shuffles its own shard
+        self._shuffle[1] += 1
+        return ops.shuffle_indices(n, self._shuffle[0], stream)
 
     # -- one update -----------------------------------------------------------------------
     def train_step(self, num_epochs, batch_size, critic_coef, entropy_coef, clip_ratio, target_div,
@@ -702,7 +718,7 @@ class PPO:
         self.last_paths = {"fused_head": bool(fused_head), "fused_gather": bool(fused_gather),
                            "fused_update": bool(fused_update)}
         for _epoch in range(num_epochs):
-            perm = torch.randperm(data_size, device=dev)       # reference :575-576 (np.random.shuffle)
+            perm = self._epoch_permutation(data_size, dev)     # reference :575-576 (np.random.shuffle)
             for start in range(0, data_size, local_batch):
                 idx = perm[start:start + local_batch]          # last minibatch may be short (:581)
                 if fused_update:                               # the update kernel gathers as it goes
@@ -848,6 +864,7 @@ class PPO:
         return {"agent": self.agent.state_dict(), "pi_optimizer": self.pi_optimizer.state_dict(),
                 "va_optimizer": self.va_optimizer.state_dict(), "vec_env": self.vec_env.state_dict(),
                 "updates": self.updates, "lr_anneal": self._lr_anneal,
+                "shuffle": list(self._shuffle) if self._shuffle is not None else None,
                 "rng_cpu": torch.get_rng_state(),
                 "rng_cuda": torch.cuda.get_rng_state() if torch.cuda.is_available() else None}
 
@@ -857,6 +874,8 @@ class PPO:
         self.va_optimizer.load_state_dict(sd["va_optimizer"])
         self.vec_env.load_state_dict(sd["vec_env"])
         self.updates, self._lr_anneal = int(sd["updates"]), float(sd["lr_anneal"])
+        shuffle = sd.get("shuffle")
+        self._shuffle = [int(shuffle[0]), int(shuffle[1])] if shuffle is not None else None
         torch.set_rng_state(sd["rng_cpu"])
         if sd["rng_cuda"] is not None and torch.cuda.is_available():
             torch.cuda.set_rng_state(sd["rng_cuda"])

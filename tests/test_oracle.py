@@ -282,3 +282,39 @@ def test_three_fma_division_by_total_mass_is_ieee_division():
     assert cref.div_by_total_mass_mismatches(150_000_000, seed=1, e_lo=-40, e_hi=20) == 0
     assert cref.div_by_total_mass_mismatches(25_000_000, seed=2, e_lo=-900, e_hi=-40) == 0
     assert cref.div_by_total_mass_mismatches(25_000_000, seed=3, e_lo=20, e_hi=1000) == 0
+
+
+def test_shuffle_restatement_is_a_uniform_looking_permutation():
+    """oracle_shuffle_indices (what ppo_shuffle_indices computes; tests/test_gpu_shuffle.py compares them bit for bit):
+    a permutation for every n; over many (seed, stream) pairs every element lands on every position equally often
+    (chi-square), neighbours do not stay neighbours, fixed points are Poisson(1), and input / output positions are
+    uncorrelated."""
+    from oracle import cref
+    for n in (1, 2, 3, 7, 8, 9, 100, 1023, 1024, 1025, 50000):
+        p = cref.shuffle_indices(n, 5, n)
+        assert np.array_equal(np.sort(p), np.arange(n)), n
+    # position uniformity, small n: counts[i, j] = how often element j sits at position i
+    trials = 4000
+    for n in (5, 8, 13):
+        counts = np.zeros((n, n))
+        for s in range(trials):
+            p = cref.shuffle_indices(n, 1000 + s, s // 7)
+            counts[np.arange(n), p] += 1
+        chi2 = ((counts - trials / n) ** 2 / (trials / n)).sum()      # (n - 1)^2 degrees of freedom
+        dof = (n - 1) ** 2
+        assert chi2 < dof + 5 * np.sqrt(2 * dof), (n, chi2, dof)
+    # a large permutation: correlation, adjacency, fixed points (averaged over streams)
+    n = 1 << 16
+    fixed, adjacent = [], []
+    for s in range(40):
+        p = cref.shuffle_indices(n, 77, s)
+        r = np.corrcoef(np.arange(n), p)[0, 1]
+        assert abs(r) < 5 / np.sqrt(n), (s, r)
+        fixed.append(int((p == np.arange(n)).sum()))
+        adjacent.append(int((np.abs(np.diff(p)) == 1).sum()))          # expected ~ 2
+    assert 0.4 < np.mean(fixed) < 1.8, np.mean(fixed)
+    assert np.mean(adjacent) < 4.0, np.mean(adjacent)
+    # a non-power-of-two size close above a power of two (cycle walking nearly every other index)
+    n = (1 << 15) + 3
+    p = cref.shuffle_indices(n, 1, 2)
+    assert np.array_equal(np.sort(p), np.arange(n)) and abs(np.corrcoef(np.arange(n), p)[0, 1]) < 0.03
