@@ -160,6 +160,14 @@ int ppo_adv_stats(const float *adv, long B, double *stats3, void *workspace,
                   size_t workspace_bytes, void *stream);
 
 /*
+ * The same statistics for the minibatch adv[idx[0 .. B-1]] without gathering it first (the index
+ * slice of src/ppo.py:581-588 applied to `advantages`; :497-500): bit-identical to ppo_adv_stats on
+ * the gathered copy.  idx [B] i64, every entry a valid row of adv (not checked).
+ */
+int ppo_adv_stats_gather(const float *adv, const long *idx, long B, double *stats3,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Fused PPO minibatch loss, forward and backward.  Replaces the ratio at
  * src/ppo.py:595 and PPO.compute_losses (src/ppo.py:490-527) plus the autograd backward
  * of both losses.

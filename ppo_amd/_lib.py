@@ -24,6 +24,7 @@ SIGNATURES = {
     "ppo_gae_ragged_noalloc": (_i, [_vp, _vp, _vp, _l, _vp, _vp, _d, _d, _vp, _i, _i, _vp, _vp]),
     "ppo_loss_workspace_bytes": (_sz, [_l]),
     "ppo_adv_stats": (_i, [_vp, _l, _vp, _vp, _sz, _vp]),
+    "ppo_adv_stats_gather": (_i, [_vp, _vp, _l, _vp, _vp, _sz, _vp]),
     "ppo_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _l, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ppo_loss_logits_fwd_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _l, _vp, _vp, _vp, _vp,
                                      _vp, _sz, _vp]),

@@ -96,7 +96,32 @@ __global__ void __launch_bounds__(LOSS_BLOCK) k_adv_stats_partial(const float *a
     block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * 2);
 }
 
-__global__ void __launch_bounds__(LOSS_BLOCK) k_adv_stats_final(const float *adv, long B, const double *partials,
+// The same sums over adv[idx[i]], i < B: thread, group and order of additions as above, so that the statistics of a
+// minibatch given by its indices equal those of the gathered copy bit for bit.
+__global__ void __launch_bounds__(LOSS_BLOCK) k_adv_stats_partial_idx(const float *adv, const long *idx, long B, double *partials)
+{
+    const float K = adv[idx[0]];
+    double acc[2] = {0.0, 0.0};
+    const long G = loss_groups(B);
+    for (long g = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x; g < G; g += (long)gridDim.x * LOSS_BLOCK) {
+        const long i = g * 4;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < B) e[k] = adv[idx[i + k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < B) {
+                const double d = (double)e[k] - (double)K;
+                acc[0] += d;
+                acc[1] += d * d;
+            }
+        }
+    }
+    block_reduce_store<2>(acc, partials + (size_t)blockIdx.x * 2);
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_adv_stats_final(const float *adv, const long *idx, long B, const double *partials,
                                                               int nblocks, double *stats3)
 {
     double acc[2] = {0.0, 0.0};
@@ -107,7 +132,7 @@ __global__ void __launch_bounds__(LOSS_BLOCK) k_adv_stats_final(const float *adv
     __shared__ double tot[2];
     block_reduce_store<2>(acc, tot);
     if (threadIdx.x == 0) {
-        const double n = (double)B, K = (double)adv[0];
+        const double n = (double)B, K = (double)adv[idx ? idx[0] : 0];
         const double S = tot[0], Q = tot[1];
         stats3[0] = n;
         stats3[1] = K + S / n;
@@ -278,7 +303,23 @@ int ppo_adv_stats(const float *adv, long B, double *stats3, void *workspace, siz
     hipLaunchKernelGGL(k_adv_stats_partial, dim3(grid), dim3(LOSS_BLOCK), 0, s, adv, B, partials, vec);
     int rc = ppo_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_adv_stats_final, dim3(1), dim3(LOSS_BLOCK), 0, s, adv, B, partials, grid, stats3);
+    hipLaunchKernelGGL(k_adv_stats_final, dim3(1), dim3(LOSS_BLOCK), 0, s, adv, (const long *)nullptr, B, partials, grid, stats3);
+    return ppo_launch_status();
+}
+
+int ppo_adv_stats_gather(const float *adv, const long *idx, long B, double *stats3, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    PPO_REQUIRE(adv && idx && stats3 && B >= 1);
+    PPO_REQUIRE(workspace && workspace_bytes >= ppo_loss_workspace_bytes(B) && ppo_aligned(workspace, 8));
+    PPO_REQUIRE(ppo_aligned(adv, 4) && ppo_aligned(idx, 8) && ppo_aligned(stats3, 8));
+    hipStream_t s = (hipStream_t)stream;
+    double *partials = reinterpret_cast<double *>(workspace);
+    const int grid = loss_grid(B);
+    hipLaunchKernelGGL(k_adv_stats_partial_idx, dim3(grid), dim3(LOSS_BLOCK), 0, s, adv, idx, B, partials);
+    int rc = ppo_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_adv_stats_final, dim3(1), dim3(LOSS_BLOCK), 0, s, adv, idx, B, partials, grid, stats3);
     return ppo_launch_status();
 }
 

@@ -108,14 +108,20 @@ def gae_ragged(rewards, values, end_values, done_flags, trunc_flags, gamma, lam,
 
 
 # --------------------------------------------------------------------------- loss
-def adv_stats(adv: torch.Tensor) -> torch.Tensor:
-    """{count, mean, M2} (fp64, device) of a flat advantage tensor (reference src/ppo.py:501)."""
+def adv_stats(adv: torch.Tensor, idx: torch.Tensor | None = None) -> torch.Tensor:
+    """{count, mean, M2} (fp64, device) of a flat advantage tensor (reference src/ppo.py:501); with idx (device
+    int64), of adv[idx] without gathering it (ppo_adv_stats_gather: the same numbers bit for bit)."""
     lib = _lib.load()
     a = _dev(adv, torch.float32).reshape(-1)
     stats = torch.empty(3, dtype=torch.float64, device=a.device)
-    ws = _workspace(lib.ppo_loss_workspace_bytes(a.numel()), a.device)
-    _lib.check(lib.ppo_adv_stats(_ptr(a), a.numel(), _ptr(stats), _ptr(ws), ws.numel(), _stream()),
-               "ppo_adv_stats")
+    n = a.numel() if idx is None else idx.numel()
+    ws = _workspace(lib.ppo_loss_workspace_bytes(n), a.device)
+    if idx is None:
+        _lib.check(lib.ppo_adv_stats(_ptr(a), n, _ptr(stats), _ptr(ws), ws.numel(), _stream()), "ppo_adv_stats")
+    else:
+        assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 1
+        _lib.check(lib.ppo_adv_stats_gather(_ptr(a), _ptr(idx), n, _ptr(stats), _ptr(ws), ws.numel(), _stream()),
+                   "ppo_adv_stats_gather")
     return stats
 
 
@@ -464,7 +470,7 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
     if idx is not None:
         assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 1
     if norm_adv and stats3 is None:
-        stats3 = adv_stats(advantages if idx is None else advantages[idx])
+        stats3 = adv_stats(advantages, idx)
     ws = _update_ws.get(dev)
     if ws is None:
         ws = _update_ws[dev] = torch.empty(lib.ppo_dense_update_workspace_bytes(), dtype=torch.uint8, device=dev)

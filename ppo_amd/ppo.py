@@ -722,7 +722,7 @@ class PPO:
             for start in range(0, data_size, local_batch):
                 idx = perm[start:start + local_batch]          # last minibatch may be short (:581)
                 if fused_update:                               # the update kernel gathers as it goes
-                    mb_adv = advantages[idx] if self.norm_adv else None
+                    mb_adv = None
                 elif fused_gather:                             # one launch for the five gathers (:582-588)
                     mb_states, mb_actions, mb_log_probs, mb_values, mb_adv = ops.minibatch_gather(
                         idx, states, actions, log_probs, values, advantages)
@@ -731,10 +731,11 @@ class PPO:
                     mb_log_probs, mb_values, mb_adv = log_probs[idx], values[idx], advantages[idx]
                 stats3 = None
                 if self.norm_adv and world > 1:                # keep minibatch normalisation global
-                    stats3 = ppo_dist.merged_adv_stats(ops.adv_stats(mb_adv))
+                    stats3 = ppo_dist.merged_adv_stats(
+                        ops.adv_stats(advantages, idx) if fused_update else ops.adv_stats(mb_adv))
                 if fused_update:
                     if self.norm_adv and stats3 is None:
-                        stats3 = ops.adv_stats(mb_adv)
+                        stats3 = ops.adv_stats(advantages, idx)
                     out5, groups = ops.dense_update_grads(
                         self.agent, states, actions, log_probs, values, advantages, clip_ratio, self.norm_adv,
                         self.clip_va_loss, c_pi=lr_anneal, c_v=critic_coef * lr_anneal, c_ent=entropy_coef * lr_anneal,

@@ -266,3 +266,17 @@ def test_logits_out_of_range_action_poisons_the_losses():
         keep = torch.ones(B, dtype=torch.bool, device="cuda")
         keep[17] = False
         assert bool(torch.isfinite(gpl[keep]).all()) and bool(torch.isfinite(gv[keep]).all())
+
+
+def test_adv_stats_gather_is_bit_identical_to_stats_of_the_gathered_copy():
+    """ppo_adv_stats_gather(adv, idx) == ppo_adv_stats(adv[idx]) bit for bit (same threads, groups and order of the
+    float64 additions), for sizes around the vector width and a C2-sized minibatch."""
+    import torch
+    from ppo_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    rows = 128 * 65536
+    adv = torch.randn(rows, device="cuda", generator=gen) * 3 + 0.7
+    for B in (1, 2, 3, 4, 5, 1023, 70001, rows // 4):
+        idx = torch.randint(0, rows, (B,), device="cuda", generator=gen)
+        a, b = ops.adv_stats(adv, idx), ops.adv_stats(adv[idx].contiguous())
+        assert torch.equal(a, b), (B, a, b)
