@@ -177,7 +177,8 @@ def train_step_rates(kind, N, T, world, seed, updates=4):
         del ppo
         torch.cuda.empty_cache()
     out["config"] = (f"{updates} updates, medians of the last {updates - 1}; num_epochs 1, batch_size T*N/4 (global), norm_adv 1, "
-                     f"clip_va_loss 1; minibatch step = ppo_dense_update_grads (fused forward + loss + backward + weight gradients)")
+                     f"clip_va_loss 1; minibatch step = ppo_dense_update_grads (fused forward + loss + backward + weight gradients, net mode of the rollout); "
+                     f"epoch shuffle = ppo_shuffle_indices, minibatch statistics = ppo_adv_stats_gather")
     return out
 
 
