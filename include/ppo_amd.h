@@ -401,6 +401,25 @@ int ppo_dense_update_grads(int obs_dim, int num_actions, int heads, int net_mode
                            float *out5, float *grads, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* ---- gradient clipping + Adam step of one optimiser group (csrc/optim.hip) --------------------
+ * Replaces, per minibatch, nn.utils.clip_grad_norm_(agent.parameters(), max_grad_norm) followed by
+ * optimizer.step() (src/ppo.py:608-609 joint; :615-616 and :625-626 split networks; the optimisers
+ * are optim.Adam(lr, eps=1e-5), :732-733) for the dense agents: ONE launch instead of PyTorch's 17.
+ *   params / exp_avg / exp_avg_sq: HOST arrays of n_tensors (<= 16) device pointers -- the group's
+ *   parameter tensors and their Adam moments, numel[k] f32 each; grads: the group's gradients in the
+ *   same order as ONE flat device buffer of sum(numel) f32 (what ppo_dense_update_grads writes),
+ *   scaled in place by the clip coefficient like clip_grad_norm_ does.
+ *   total_norm = sqrt(sum g^2) (f64 sum); coef = min(max_grad_norm / (total_norm + 1e-6), 1)
+ *   (max_grad_norm < 0: no clipping); then torch's Adam (no weight decay, no amsgrad):
+ *   m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps),  step = 1, 2, ...
+ *   in f32, one rounding per operation.  One workgroup: sum(numel) <= 2^22.
+ */
+int ppo_clip_adam_step(int n_tensors, float *const *params, float *const *exp_avg,
+                       float *const *exp_avg_sq, const long *numel, float *grads,
+                       double max_grad_norm, double lr, double beta1, double beta2, double eps,
+                       long step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

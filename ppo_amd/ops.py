@@ -7,6 +7,7 @@ with no HIP device every op raises.
 """
 from __future__ import annotations
 
+import ctypes as C
 import functools
 import os
 
@@ -507,3 +508,54 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
         run(agent.pi_backbone, 1)
         run(agent.va_backbone, 2)
     return out5, groups
+
+
+# ---- gradient clipping + Adam step in one launch (csrc/optim.hip) ---------------------------------
+def clip_adam_supported(opt) -> bool:
+    """ppo_clip_adam_step covers the reference's optimiser as it is built (optim.Adam(lr, eps=1e-5),
+    src/ppo.py:732-733): plain Adam, one parameter group, no weight decay / amsgrad / maximize."""
+    if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+        return False
+    g = opt.param_groups[0]
+    return not (g.get("amsgrad") or g.get("maximize") or g.get("weight_decay") or g.get("capturable")
+                or g.get("fused") or g.get("differentiable")) and not isinstance(g["lr"], torch.Tensor)
+
+
+def clip_adam_step(opt, group: "GradGroup", max_grad_norm: float):
+    """nn.utils.clip_grad_norm_(params of `group`, max_grad_norm); opt.step() for the (parameter, gradient)
+    pairs of one dense_update_grads launch, as ONE kernel on the group's flat gradient bucket (reference
+    src/ppo.py:608-609).  Works on torch.optim.Adam's own state tensors (created here the way Adam's first
+    step() creates them), so state_dict / load_state_dict and a later plain opt.step() see the same state."""
+    lib = _lib.load()
+    params = [p for p, _ in group]
+    key = tuple(id(p) for p in params)
+    cache = opt.__dict__.setdefault("_ppo_clip_adam", {})
+    ent = cache.get(key)
+    states = [opt.state[p] for p in params]
+    if ent is None or any(st.get("exp_avg") is not m for st, m in zip(states, ent["m"])):
+        for p, st in zip(params, states):
+            if len(st) == 0:                       # torch/optim/adam.py _init_group
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            for t in (p, st["exp_avg"], st["exp_avg_sq"]):
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+            assert st["step"].device.type == "cpu"
+        n = len(params)
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ent = cache[key] = {"m": [st["exp_avg"] for st in states], "v": [st["exp_avg_sq"] for st in states],
+                            "steps": [st["step"] for st in states], "n": n,
+                            "p_arr": arr(params), "numel": (C.c_long * n)(*[p.numel() for p in params])}
+        ent["m_arr"], ent["v_arr"] = arr(ent["m"]), arr(ent["v"])
+    g = opt.param_groups[0]
+    torch._foreach_add_(ent["steps"], 1)
+    step = int(ent["steps"][0].item())
+    flat = group.flat
+    assert flat.is_cuda and flat.dtype == torch.float32 and flat.numel() == sum(p.numel() for p in params)
+    rc = lib.ppo_clip_adam_step(ent["n"], ent["p_arr"], ent["m_arr"], ent["v_arr"], ent["numel"], flat.data_ptr(),
+                                float(max_grad_norm), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                float(g["eps"]), step, _stream())
+    _lib.check(rc, "ppo_clip_adam_step")
+    # the parameters changed in place behind autograd's back: bump their version counters like an in-place
+    # torch op would (SyncVecEnv.prepack keys the packed rollout parameters on them)
+    torch._C._autograd._unsafe_set_version_counter(params, [p._version + 1 for p in params])

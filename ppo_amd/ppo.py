@@ -632,6 +632,8 @@ class PPO:
         # dense Discrete agents (CartPole / Acrobot): the whole minibatch step in one kernel; PPO_AMD_FUSED_UPDATE=0
         # keeps the PyTorch MLP around the loss kernel
         self.fused_dense_update = os.environ.get("PPO_AMD_FUSED_UPDATE", "1") != "0"
+        # with it: clip_grad_norm_ + Adam.step of a minibatch as one launch (ppo_clip_adam_step) instead of PyTorch's 17
+        self.fused_optimizer = os.environ.get("PPO_AMD_FUSED_OPTIMIZER", "1") != "0"
         # the epoch's shuffled index list from ppo_shuffle_indices (one pass; torch.randperm's 64-bit key sort costs
         # more than a minibatch step at C2 scale); PPO_AMD_SHUFFLE=torch keeps torch.randperm
         self.device_shuffle = os.environ.get("PPO_AMD_SHUFFLE", "kernel") != "torch"
@@ -715,8 +717,10 @@ class PPO:
         # its 64 x 64 products in the arithmetic the rollout just ran with: the split kernels inside the limits
         # checked when the parameters were packed (ops.split_ok), exact f32 products otherwise
         upd_mode = ops.NET_F16_SPLIT if ve.net_mode_used == ops.NET_F16_SPLIT else ops.NET_F32
+        fused_opt = (fused_update and self.fused_optimizer and ops.clip_adam_supported(self.pi_optimizer)
+                     and ops.clip_adam_supported(self.va_optimizer))
         self.last_paths = {"fused_head": bool(fused_head), "fused_gather": bool(fused_gather),
-                           "fused_update": bool(fused_update)}
+                           "fused_update": bool(fused_update), "fused_optimizer": bool(fused_opt)}
         for _epoch in range(num_epochs):
             perm = self._epoch_permutation(data_size, dev)     # reference :575-576 (np.random.shuffle)
             for start in range(0, data_size, local_batch):
@@ -757,8 +761,11 @@ class PPO:
                         for prm, grad in grp:
                             prm.grad = grad
                         ppo_dist.allreduce_flat(grp.flat)       # the group's gradients are views of one bucket
-                        nn.utils.clip_grad_norm_(params, max_grad_norm)
-                        opt.step()
+                        if fused_opt:                           # :608-609 as one launch on that bucket
+                            ops.clip_adam_step(opt, grp, max_grad_norm)
+                        else:
+                            nn.utils.clip_grad_norm_(params, max_grad_norm)
+                            opt.step()
                     if not self.joint_network:
                         critic_loss = critic_coef * critic_loss
                 elif self.joint_network:                       # reference :602-609
