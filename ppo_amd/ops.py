@@ -450,7 +450,7 @@ def dense_update_supported(agent) -> bool:
 
 
 def dense_update_grads(agent, states, actions, old_log_probs, old_values, advantages, clip_ratio, norm_adv, clip_va_loss,
-                       c_pi, c_v, c_ent, stats3=None, idx=None, net_mode: int = NET_F32):
+                       c_pi, c_v, c_ent, stats3=None, idx=None, net_mode: int = NET_F32, out5=None):
     """ppo_dense_update_grads for a ppo_amd Agent: one launch per backbone.
     Returns (out5, groups): out5 = device f32[5] {policy_loss, value_loss, clip_frac, kl_div, entropy};
     groups = one list of (parameter, gradient tensor) per launch -- [all parameters] for a joint network,
@@ -458,7 +458,8 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
     views of one flat buffer per launch.  Gradient of  c_pi policy_loss + c_v value_loss - c_ent entropy.
     idx (int64 [B], optional): the minibatch is rows idx of the given (flattened rollout) tensors -- the kernel
     gathers as it goes (reference src/ppo.py:582-588); the advantage statistics are those of the minibatch.
-    net_mode: NET_F32, or NET_F16_SPLIT for parameter sets inside the split mode's limits (split_ok)."""
+    net_mode: NET_F32, or NET_F16_SPLIT for parameter sets inside the split mode's limits (split_ok).
+    out5: where to write out5 (device f32[5], e.g. a row of a per-update table) instead of a new tensor."""
     lib = _lib.load()
     assert net_mode in (NET_F32, NET_F16_SPLIT)
     dev = states.device
@@ -475,7 +476,9 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
     ws = _update_ws.get(dev)
     if ws is None:
         ws = _update_ws[dev] = torch.empty(lib.ppo_dense_update_workspace_bytes(), dtype=torch.uint8, device=dev)
-    out5 = torch.zeros(5, dtype=torch.float32, device=dev)
+    if out5 is None:       # (every entry is written: heads = 3 by one launch, heads = 1 and 2 by the two of a split network)
+        out5 = torch.empty(5, dtype=torch.float32, device=dev)
+    assert out5.is_cuda and out5.dtype == torch.float32 and out5.is_contiguous() and out5.numel() == 5
     groups = []
 
     def run(backbone, heads):

@@ -484,11 +484,35 @@ class SyncVecEnv:
     def _stat(self, key):
         self._flush_stats()
         if self._stats_dev is not None:                 # one device->host copy for all five values
-            v = self._stats_dev.cpu().numpy()
-            self._stats_dev = None
-            self._stats_host = {"max": np.float32(v[0]), "lower": v[1], "median": v[2], "upper": v[3],
-                                "length": v[4]}
+            self._note_stats(self._stats_dev.cpu().numpy())
         return self._stats_host[key]
+
+    def _note_stats(self, v):
+        self._stats_dev = None
+        self._stats_host = {"max": np.float32(v[0]), "lower": np.float64(v[1]), "median": np.float64(v[2]),
+                            "upper": np.float64(v[3]), "length": np.float64(v[4])}
+
+    def pending_device_scalars(self):
+        """(f64 device tensor or None, callback): the episode statistics and the reward sum of the last rollout
+        that still live on the device, for a caller that copies scalars of its own to the host anyway
+        (PPO.train_step: ONE device->host copy per update instead of three); the callback takes the host values."""
+        self._flush_stats()
+        parts, takers = [], []
+        if self._stats_dev is not None:
+            parts.append(self._stats_dev)
+            takers.append((5, self._note_stats))
+        if isinstance(self._total_return, torch.Tensor) and self._total_return.dtype == torch.float64:
+            parts.append(self._total_return.reshape(1))
+            takers.append((1, lambda v: setattr(self, "_total_return", np.float32(v[0]))))
+        if not parts:
+            return None, lambda host: None
+
+        def take(host):
+            at = 0
+            for n, fn in takers:
+                fn(np.asarray(host[at:at + n], dtype=np.float64))
+                at += n
+        return (parts[0] if len(parts) == 1 else torch.cat(parts)), take
 
     max_ep_return = property(lambda self: self._stat("max"),
                              lambda self, v: self._stats_host.__setitem__("max", v))
@@ -640,6 +664,7 @@ class PPO:
         self._shuffle = None         # [seed, epochs shuffled so far]: the permutation is a function of the two
         self.minibatch_hook = None   # tests: called with a dict per minibatch (indices, losses) when set
         self._idle = False           # True while nothing of ours is queued on the device (set by a host read-back)
+        self._param_list = None      # list(agent.parameters()), built on first use
 
     # -- hot path: GAE --------------------------------------------------------------------
     def compute_advantages(self, rewards, values, end_values, done_flags, trunc_flags):
@@ -703,10 +728,12 @@ class PPO:
         dev = states.device
 
         updates_start = time.time()
-        early = torch.zeros((), dtype=torch.bool, device=dev)
-        clip_sum = torch.zeros((), dtype=torch.float32, device=dev)
+        early = torch.zeros((), dtype=torch.bool, device=dev) if target_div is not None else None
+        clip_terms = []                                        # clip_frac of every minibatch, summed once at the end
         grad_steps_done = 0
-        params = [p for p in self.agent.parameters()]
+        if self._param_list is None or self._param_list[0] is not self.agent:
+            self._param_list = (self.agent, [p for p in self.agent.parameters()])
+        params = self._param_list[1]
         fused_head = (self.fused_discrete_loss and self.agent.discrete and self.agent.action_space.n <= 8
                       and actions.dtype == torch.int32)
         fused_gather = (dev.type == "cuda" and actions.dtype in (torch.int32, torch.float32)
@@ -721,6 +748,9 @@ class PPO:
                      and ops.clip_adam_supported(self.va_optimizer))
         self.last_paths = {"fused_head": bool(fused_head), "fused_gather": bool(fused_gather),
                            "fused_update": bool(fused_update), "fused_optimizer": bool(fused_opt)}
+        # one row of {policy_loss, value_loss, clip_frac, kl_div, entropy} per minibatch, written by the update kernel
+        out_rows = (torch.empty((num_epochs * ((data_size + local_batch - 1) // local_batch), 5), dtype=torch.float32,
+                                device=dev) if fused_update else None)
         for _epoch in range(num_epochs):
             perm = self._epoch_permutation(data_size, dev)     # reference :575-576 (np.random.shuffle)
             for start in range(0, data_size, local_batch):
@@ -743,7 +773,7 @@ class PPO:
                     out5, groups = ops.dense_update_grads(
                         self.agent, states, actions, log_probs, values, advantages, clip_ratio, self.norm_adv,
                         self.clip_va_loss, c_pi=lr_anneal, c_v=critic_coef * lr_anneal, c_ent=entropy_coef * lr_anneal,
-                        stats3=stats3, idx=idx, net_mode=upd_mode)
+                        stats3=stats3, idx=idx, net_mode=upd_mode, out5=out_rows[grad_steps_done])
                     policy_loss, critic_loss, clip_frac, kl_div, entropy = out5.unbind(0)
                 elif fused_head:   # Categorical log-prob + entropy + ratio + losses in one pass (:186-216, :595-599)
                     logits, new_values = self.agent.policy_and_values(mb_states)
@@ -791,7 +821,7 @@ class PPO:
                 if target_div is not None:                     # reference :628-629
                     kl_all = ppo_dist.mean_scalar(kl_div.detach())
                     early = early | (kl_all > target_div).to(dev)
-                clip_sum += clip_frac.detach().to(dev)
+                clip_terms.append(clip_frac.detach())
                 grad_steps_done += 1
                 if self.minibatch_hook is not None:
                     self.minibatch_hook(dict(update=self.updates, epoch=_epoch, start=start, idx=idx,
@@ -803,13 +833,23 @@ class PPO:
         # rollout bracket of the next update starts with a kernel launch, not with host-side packing
         diag = ve.prepack() if (ve.native and ve.fused_rollout and dev.type == "cuda") else None
         # one device->host copy for every scalar of this update (it is also the update's final sync)
+        # -- together with the rollout's episode statistics and reward sum when those still live on the device
+        clip_sum = torch.stack(clip_terms).sum(dtype=torch.float32).to(dev)
         scalars = [policy_loss.detach().to(dev), critic_loss.detach().to(dev), entropy.detach().to(dev),
                    kl_div.detach().to(dev), clip_sum]
+        pieces = [torch.stack([s.to(torch.float32).reshape(()) for s in scalars])]
         if diag is not None:
-            scalars += [diag[0].to(dev), diag[1].to(dev), diag[2].to(dev)]
-        host = torch.stack([s.to(torch.float32).reshape(()) for s in scalars]).cpu().tolist()
+            pieces.append(diag.to(dev))
+        ve_vals, ve_take = ve.pending_device_scalars() if (ve.native and dev.type == "cuda") else (None, None)
+        if ve_vals is not None and ve_vals.device == dev:
+            pieces.append(ve_vals)                             # f64: torch.cat promotes the f32 pieces exactly
+        else:
+            ve_take = None
+        host = (pieces[0] if len(pieces) == 1 else torch.cat(pieces)).cpu().tolist()
         if diag is not None:
             ve.note_split_diag(host[5:8])
+        if ve_take is not None:
+            ve_take(host[5 + (3 if diag is not None else 0):])
         updates_time = ppo_dist.max_scalar(time.time() - updates_start)
         self._idle = dev.type == "cuda" and world == 1
         grad_steps_per_sec = grad_steps_done / updates_time
@@ -948,7 +988,9 @@ class PPO:
                 pbar.set_postfix({"pi_loss": f"{pi_loss:.3f}", "va_loss": f"{va_loss:.3f}",
                                   "entropy": f"{entropy:.3f}", "return": f"{roll_return:.3f}",
                                   "max_ep_ret": f"{ep_return_max:.3f}", "kl_div": f"{kl_div:.4f}",
-                                  "clip_frac": f"{clip_frac:.3f}"})
+                                  "clip_frac": f"{clip_frac:.3f}"}, refresh=False)
+                # (refresh=False: the bar redraws at tqdm's own rate limit, 10 Hz, instead of once per update --
+                # a forced redraw is ~0.1 ms of host time between two updates while the device waits)
             if early_stop_reward is not None and ep_return_max >= early_stop_reward:
                 if pbar is not None:
                     pbar.close()

@@ -62,7 +62,7 @@ def test_image_env_conv_agent_one_update():
     assert bool(ended[-1].all()) and ve.end_states.shape == (int(ended.sum()), 84, 84, 4)
     assert int(ve.trunc_flags[:-1].sum()) > 0 and int(ve.done_flags.sum()) > 0
     # the GPU kernels were on the path: one-launch gather (wide rows) and the fused logits loss
-    assert ppo.last_paths == {"fused_head": True, "fused_gather": True, "fused_update": False}   # conv net: PyTorch MLP around the loss kernel
+    assert ppo.last_paths == {"fused_head": True, "fused_gather": True, "fused_update": False, "fused_optimizer": False}   # conv net: PyTorch MLP around the loss kernel
     m = ppo.last_metrics
     assert np.isfinite(m["losses/policy_loss"]) and np.isfinite(m["losses/critic_loss"]) and m["losses/entropy"] > 1.0
     assert ve.median_ep_length in (23.0, 24.0, 25.0, 26.0, 27.0)
