@@ -240,6 +240,21 @@ int ppo_minibatch_gather(const int64_t *idx, long B, long M, const void *states,
 int ppo_shuffle_indices(long n, uint64_t seed, uint64_t stream_id, int64_t *idx_out, void *stream);
 
 /*
+ * Advantage statistics of EVERY minibatch of an epoch in one pass: stats3 [num_mb][3] f64 =
+ * {count, mean, M2} (as ppo_adv_stats) of adv[idx[m * batch : (m + 1) * batch]], m = 0 .. num_mb - 1,
+ * num_mb = ceil(n / batch) <= 8, where idx is the permutation ppo_shuffle_indices(n, seed, stream_id)
+ * writes -- the minibatch slices of src/ppo.py:578-588, whose advantages compute_losses normalises with
+ * their own mean / std (:501).  idx itself is not read: the permutation's bijection is run backwards,
+ * element j belongs to minibatch inverse(j) / batch, so adv is streamed once, coalesced, instead of being
+ * gathered once per minibatch (a 64-byte sector per 4-byte value).  f64 shifted sums in a fixed order
+ * (deterministic); equal to ppo_adv_stats_gather on the same slices up to f64 summation order.
+ * workspace: ppo_adv_stats_epoch_workspace_bytes() bytes, 8-byte aligned.
+ */
+size_t ppo_adv_stats_epoch_workspace_bytes(void);
+int ppo_adv_stats_epoch(const float *adv, long n, uint64_t seed, uint64_t stream_id, long batch,
+                        double *stats3, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Weight and bias gradient of y = x W^T + b for a small layer (M, K <= 64) over a huge batch:
  * dW[M,K] = sum_b g[b,m] x[b,k], db[M] = sum_b g[b,m] (db may be NULL).  Replaces the weight-gradient
  * GEMMs inside loss.backward() of the update phase (src/ppo.py:606-607, :614-615, :623-624) for the

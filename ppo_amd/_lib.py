@@ -32,6 +32,8 @@ SIGNATURES = {
     "ppo_dense_update_grad_floats": (_sz, [_i, _i, _i]),
     "ppo_dense_update_grads": (_i, [_i, _i, _i, _i] + [_vp] * 8 + [_vp] * 6 + [_vp, _d, _i, _i, _l, _d, _d, _d, _vp, _vp, _vp, _sz, _vp]),
     "ppo_shuffle_indices": (_i, [_l, _u64, _u64, _vp, _vp]),
+    "ppo_adv_stats_epoch_workspace_bytes": (_sz, []),
+    "ppo_adv_stats_epoch": (_i, [_vp, _l, _u64, _u64, _l, _vp, _vp, _sz, _vp]),
     "ppo_clip_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _l, _vp]),
     "ppo_minibatch_gather": (_i, [_vp, _l, _l, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ppo_linear_wgrad_workspace_bytes": (_sz, [_l]),

@@ -125,6 +125,132 @@ void host_philox4x32_10(const uint32_t c_in[4], uint32_t k0, uint32_t k1, uint32
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// The keys of the permutation of [0, n) that (seed, stream_id) select.
+ShuffleKeys make_shuffle_keys(long n, uint64_t seed, uint64_t stream_id)
+{
+    ShuffleKeys q;
+    int k = 2;
+    while (k < 32 && (1L << k) < n) ++k;
+    q.mask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    q.sh_a = (k + 1) / 2;
+    q.sh_b = k / 3 > 1 ? k / 3 : 1;
+    // key half 1 is offset so that this stream never collides with the reset / sampling streams of the same seed
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ 0x2545F491u;
+    uint32_t w[12];
+    for (uint32_t b = 0; b < 3; ++b) {
+        const uint32_t ctr[4] = {(uint32_t)stream_id, (uint32_t)(stream_id >> 32), b, 0x5348464Cu};
+        host_philox4x32_10(ctr, k0, k1, w + 4 * b);
+    }
+    for (int r = 0; r < SHUF_ROUNDS; ++r) {
+        q.mul[r] = w[r] | 1u;
+        q.add[r] = w[SHUF_ROUNDS + r];
+    }
+    return q;
+}
+
+// ---- advantage statistics of every minibatch of an epoch in one streaming pass -------------------
+// The minibatches of an epoch are slices of the shuffled indices (reference src/ppo.py:575-588), and
+// compute_losses normalises each minibatch's advantages with its own mean / std (:501).  Gathering
+// adv[idx] per minibatch reads a 64-byte sector for every 4-byte value (43 us per 2 M-sample minibatch at
+// BASELINE configs[1], four times per epoch).  The permutation is a keyed bijection, so it can be run
+// BACKWARDS instead: element j of the flat rollout sits at position inv(j) of the shuffled order, i.e. in
+// minibatch inv(j) / batch -- one coalesced pass over adv serves all minibatches of the epoch at once.
+// Each step of shuffle_bijection is inverted exactly: x ^= x >> s by the doubling series, the affine step
+// by the multiplier's inverse modulo 2^k (Newton's iteration on the host); cycle walking works the same
+// way in reverse.  Shifted sums as in loss.hip (K = adv[0]); per-thread f64 accumulators live in LDS
+// ([minibatch][sum, sum of squares][thread]: conflict-free), blocks and threads add in a fixed order.
+constexpr int EPOCH_MAX_MB = 8;
+constexpr int EPOCH_BLOCK = 256;
+constexpr int EPOCH_GRID = 1024;
+
+struct ShuffleInvKeys {
+    uint32_t inv[SHUF_ROUNDS], add[SHUF_ROUNDS];
+    uint32_t mask;
+    int sh_a, sh_b, k;
+};
+
+__device__ __forceinline__ uint32_t undo_xorshift(uint32_t y, int s, int k)
+{
+    for (int t = s; t < k; t <<= 1) y ^= y >> t;
+    return y;
+}
+
+__device__ __forceinline__ uint32_t shuffle_bijection_inv(uint32_t y, const ShuffleInvKeys &q)
+{
+    y = undo_xorshift(y, q.sh_a, q.k);
+#pragma unroll
+    for (int r = SHUF_ROUNDS - 1; r >= 0; --r) {
+        y = ((y - q.add[r]) * q.inv[r]) & q.mask;
+        y = undo_xorshift(y, (r & 1) ? q.sh_b : q.sh_a, q.k);
+    }
+    return y;
+}
+
+__global__ void __launch_bounds__(EPOCH_BLOCK) k_adv_stats_epoch(ShuffleInvKeys q, const float *adv, long n, long batch,
+                                                                  int num_mb, double *partials)
+{
+    __shared__ double slot[EPOCH_MAX_MB * 2][EPOCH_BLOCK];
+    const int tid = threadIdx.x;
+    for (int c = 0; c < num_mb * 2; ++c) slot[c][tid] = 0.0;
+    const double K = (double)adv[0];
+    const long stride = (long)gridDim.x * EPOCH_BLOCK;
+    for (long j0 = (long)blockIdx.x * EPOCH_BLOCK + tid; j0 < n; j0 += 4 * stride) {
+        float e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = j0 + u * stride < n ? adv[j0 + u * stride] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long j = j0 + u * stride;
+            if (j < n) {
+                uint32_t x = (uint32_t)j;
+                do x = shuffle_bijection_inv(x, q);
+                while ((long)x >= n);                  // cycle walking, backwards
+                int mb = 0;
+                for (int m = 1; m < num_mb; ++m) mb += (long)x >= m * batch;
+                const double d = (double)e[u] - K;
+                slot[2 * mb][tid] += d;
+                slot[2 * mb + 1][tid] += d * d;
+            }
+        }
+    }
+    // this block's sums: every wave reduces its threads' slots, thread 0 adds the waves in order
+    __shared__ double part[EPOCH_BLOCK / PPO_WAVE][EPOCH_MAX_MB * 2];
+    for (int c = 0; c < num_mb * 2; ++c) {
+        const double w = wave_sum(slot[c][tid]);
+        if ((tid & (PPO_WAVE - 1)) == 0) part[tid / PPO_WAVE][c] = w;
+    }
+    __syncthreads();
+    if (tid < num_mb * 2) {
+        double t = 0.0;
+        for (int w = 0; w < EPOCH_BLOCK / PPO_WAVE; ++w) t += part[w][tid];
+        partials[(size_t)blockIdx.x * (EPOCH_MAX_MB * 2) + tid] = t;
+    }
+}
+
+__global__ void __launch_bounds__(EPOCH_BLOCK) k_adv_stats_epoch_final(const float *adv, long n, long batch, int num_mb,
+                                                                        const double *partials, int nblocks, double *stats3)
+{
+    __shared__ double part[EPOCH_BLOCK / PPO_WAVE][EPOCH_MAX_MB * 2];
+    const int tid = threadIdx.x;
+    for (int c = 0; c < num_mb * 2; ++c) {
+        double a = 0.0;
+        for (int b = tid; b < nblocks; b += EPOCH_BLOCK) a += partials[(size_t)b * (EPOCH_MAX_MB * 2) + c];
+        a = wave_sum(a);
+        if ((tid & (PPO_WAVE - 1)) == 0) part[tid / PPO_WAVE][c] = a;
+    }
+    __syncthreads();
+    if (tid < num_mb) {
+        double S = 0.0, Q = 0.0;
+        for (int w = 0; w < EPOCH_BLOCK / PPO_WAVE; ++w) { S += part[w][2 * tid]; Q += part[w][2 * tid + 1]; }
+        const long lo = tid * batch, hi = lo + batch < n ? lo + batch : n;
+        const double cnt = (double)(hi - lo), K = (double)adv[0];
+        stats3[3 * tid + 0] = cnt;
+        stats3[3 * tid + 1] = K + S / cnt;
+        const double m2 = Q - S * S / cnt;
+        stats3[3 * tid + 2] = m2 > 0.0 ? m2 : 0.0;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -177,26 +303,43 @@ int ppo_shuffle_indices(long n, uint64_t seed, uint64_t stream_id, int64_t *idx_
     PPO_REQUIRE(n >= 0 && n <= (1L << 32));
     if (n == 0) return 0;
     PPO_REQUIRE(idx_out && ppo_aligned(idx_out, 8));
-    ShuffleKeys q;
-    int k = 2;
-    while (k < 32 && (1L << k) < n) ++k;
-    q.mask = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
-    q.sh_a = (k + 1) / 2;
-    q.sh_b = k / 3 > 1 ? k / 3 : 1;
-    // key half 1 is offset so that this stream never collides with the reset / sampling streams of the same seed
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ 0x2545F491u;
-    uint32_t w[12];
-    for (uint32_t b = 0; b < 3; ++b) {
-        const uint32_t ctr[4] = {(uint32_t)stream_id, (uint32_t)(stream_id >> 32), b, 0x5348464Cu};
-        host_philox4x32_10(ctr, k0, k1, w + 4 * b);
-    }
-    for (int r = 0; r < SHUF_ROUNDS; ++r) {
-        q.mul[r] = w[r] | 1u;
-        q.add[r] = w[SHUF_ROUNDS + r];
-    }
+    const ShuffleKeys q = make_shuffle_keys(n, seed, stream_id);
     long blocks = (n + MB_BLOCK - 1) / MB_BLOCK;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_shuffle_indices, dim3((unsigned)blocks), dim3(MB_BLOCK), 0, (hipStream_t)stream, q, n, idx_out);
+    return ppo_launch_status();
+}
+
+size_t ppo_adv_stats_epoch_workspace_bytes(void) { return (size_t)EPOCH_GRID * EPOCH_MAX_MB * 2 * sizeof(double); }
+
+int ppo_adv_stats_epoch(const float *adv, long n, uint64_t seed, uint64_t stream_id, long batch, double *stats3,
+                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    PPO_REQUIRE(n >= 1 && n <= (1L << 32) && batch >= 1);
+    const long num_mb = (n + batch - 1) / batch;
+    PPO_REQUIRE(num_mb <= EPOCH_MAX_MB);
+    PPO_REQUIRE(adv && stats3 && workspace && ppo_aligned(stats3, 8) && ppo_aligned(workspace, 8));
+    PPO_REQUIRE(workspace_bytes >= ppo_adv_stats_epoch_workspace_bytes());
+    const ShuffleKeys f = make_shuffle_keys(n, seed, stream_id);
+    ShuffleInvKeys q;
+    q.mask = f.mask; q.sh_a = f.sh_a; q.sh_b = f.sh_b;
+    q.k = 2;
+    while (q.k < 32 && (1L << q.k) < n) ++q.k;
+    for (int r = 0; r < SHUF_ROUNDS; ++r) {
+        uint32_t inv = f.mul[r];                               // odd a: a * a = 1 mod 8, each Newton step doubles the bits
+        for (int it = 0; it < 5; ++it) inv *= 2u - f.mul[r] * inv;
+        q.inv[r] = inv;
+        q.add[r] = f.add[r];
+    }
+    long blocks = (n + EPOCH_BLOCK * 4 - 1) / (EPOCH_BLOCK * 4);
+    if (blocks > EPOCH_GRID) blocks = EPOCH_GRID;
+    hipStream_t s = (hipStream_t)stream;
+    double *partials = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(k_adv_stats_epoch, dim3((unsigned)blocks), dim3(EPOCH_BLOCK), 0, s, q, adv, n, batch, (int)num_mb, partials);
+    int rc = ppo_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_adv_stats_epoch_final, dim3(1), dim3(EPOCH_BLOCK), 0, s, adv, n, batch, (int)num_mb,
+                       (const double *)partials, (int)blocks, stats3);
     return ppo_launch_status();
 }
 

@@ -254,6 +254,30 @@ def shuffle_indices(n: int, seed: int, stream_id: int, out: torch.Tensor | None 
     return out
 
 
+ADV_STATS_EPOCH_MAX_MB = 8
+_epoch_ws = {}
+
+
+def adv_stats_epoch(adv: torch.Tensor, seed: int, stream_id: int, batch: int) -> torch.Tensor:
+    """ppo_adv_stats_epoch: [num_mb, 3] f64 {count, mean, M2} of adv[perm[m * batch:(m + 1) * batch]] for every
+    minibatch m of the epoch whose permutation is shuffle_indices(adv.numel(), seed, stream_id) -- one coalesced
+    pass over adv instead of one gather per minibatch (reference src/ppo.py:578-588, :501)."""
+    lib = _lib.load()
+    a = adv.reshape(-1)
+    assert a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()
+    n = a.numel()
+    num_mb = (n + batch - 1) // batch
+    assert 1 <= num_mb <= ADV_STATS_EPOCH_MAX_MB
+    ws = _epoch_ws.get(a.device)
+    if ws is None:
+        ws = _epoch_ws[a.device] = torch.empty(lib.ppo_adv_stats_epoch_workspace_bytes(), dtype=torch.uint8, device=a.device)
+    out = torch.empty((num_mb, 3), dtype=torch.float64, device=a.device)
+    rc = lib.ppo_adv_stats_epoch(_ptr(a), n, int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1), int(batch), _ptr(out),
+                                 _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "ppo_adv_stats_epoch")
+    return out
+
+
 def minibatch_gather(idx, states, actions, log_probs, values, adv, check_index=False):
     """(states[idx], actions[idx], log_probs[idx], values[idx], adv[idx]) in one launch
     (reference src/ppo.py:582-588).  All inputs are flattened-rollout tensors with M rows."""

@@ -658,6 +658,8 @@ class PPO:
         self.fused_dense_update = os.environ.get("PPO_AMD_FUSED_UPDATE", "1") != "0"
         # with it: clip_grad_norm_ + Adam.step of a minibatch as one launch (ppo_clip_adam_step) instead of PyTorch's 17
         self.fused_optimizer = os.environ.get("PPO_AMD_FUSED_OPTIMIZER", "1") != "0"
+        self.fused_epoch_stats = os.environ.get("PPO_AMD_EPOCH_STATS", "1") != "0"   # ops.adv_stats_epoch, see train_step
+        self._last_perm_keys = None
         # the epoch's shuffled index list from ppo_shuffle_indices (one pass; torch.randperm's 64-bit key sort costs
         # more than a minibatch step at C2 scale); PPO_AMD_SHUFFLE=torch keeps torch.randperm
         self.device_shuffle = os.environ.get("PPO_AMD_SHUFFLE", "kernel") != "torch"
@@ -682,6 +684,7 @@ class PPO:
 
     def _epoch_permutation(self, n: int, dev) -> torch.Tensor:
         """reference src/ppo.py:575-576 (np.random.shuffle(indices)): the rows of this rank's rollout in random order."""
+        self._last_perm_keys = None
         if dev.type != "cuda" or not self.device_shuffle:
             return torch.randperm(n, device=dev)
         if self._shuffle is None:
@@ -690,6 +693,7 @@ class PPO:
             self._shuffle = [seed, 0]
         stream = (ppo_dist.rank() << 40) + self._shuffle[1]          # every rank shuffles its own shard
         self._shuffle[1] += 1
+        self._last_perm_keys = (self._shuffle[0], stream)              # what ops.adv_stats_epoch needs to follow it
         return ops.shuffle_indices(n, self._shuffle[0], stream)
 
     # -- one update -----------------------------------------------------------------------
@@ -753,6 +757,12 @@ class PPO:
                                 device=dev) if fused_update else None)
         for _epoch in range(num_epochs):
             perm = self._epoch_permutation(data_size, dev)     # reference :575-576 (np.random.shuffle)
+            # the advantage statistics of all of the epoch's minibatches from one streaming pass (the device
+            # shuffle's bijection run backwards) instead of one gather per minibatch
+            epoch_stats = None
+            if (fused_update and self.norm_adv and self._last_perm_keys is not None and self.fused_epoch_stats
+                    and (data_size + local_batch - 1) // local_batch <= ops.ADV_STATS_EPOCH_MAX_MB):
+                epoch_stats = ops.adv_stats_epoch(advantages, *self._last_perm_keys, local_batch)
             for start in range(0, data_size, local_batch):
                 idx = perm[start:start + local_batch]          # last minibatch may be short (:581)
                 if fused_update:                               # the update kernel gathers as it goes
@@ -764,12 +774,14 @@ class PPO:
                     mb_states, mb_actions = states[idx], actions[idx]
                     mb_log_probs, mb_values, mb_adv = log_probs[idx], values[idx], advantages[idx]
                 stats3 = None
+                local3 = epoch_stats[start // local_batch] if epoch_stats is not None else None
                 if self.norm_adv and world > 1:                # keep minibatch normalisation global
                     stats3 = ppo_dist.merged_adv_stats(
-                        ops.adv_stats(advantages, idx) if fused_update else ops.adv_stats(mb_adv))
+                        local3 if local3 is not None else
+                        (ops.adv_stats(advantages, idx) if fused_update else ops.adv_stats(mb_adv)))
                 if fused_update:
                     if self.norm_adv and stats3 is None:
-                        stats3 = ops.adv_stats(advantages, idx)
+                        stats3 = local3 if local3 is not None else ops.adv_stats(advantages, idx)
                     out5, groups = ops.dense_update_grads(
                         self.agent, states, actions, log_probs, values, advantages, clip_ratio, self.norm_adv,
                         self.clip_va_loss, c_pi=lr_anneal, c_v=critic_coef * lr_anneal, c_ent=entropy_coef * lr_anneal,

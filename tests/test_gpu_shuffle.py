@@ -57,3 +57,46 @@ def test_shuffle_rejects_bad_arguments():
     assert lib.ppo_shuffle_indices(-1, 1, 1, out.data_ptr(), None) == 1
     assert lib.ppo_shuffle_indices((1 << 32) + 1, 1, 1, out.data_ptr(), None) == 1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n,batch", [(8, 3), (1000, 256), (4097, 4097), (4097, 1025), (65536, 8192), (100003, 20000),
+                                     (1 << 20, 1 << 18), (8388608, 2097152), (8388609, 1048577)])
+def test_epoch_advantage_statistics_follow_the_permutation(n, batch):
+    """ppo_adv_stats_epoch (the shuffle's bijection run backwards, one streaming pass) against ppo_adv_stats_gather
+    on the slices of the permutation ppo_shuffle_indices writes, and against numpy in float64: counts exact, mean
+    and M2 to f64 summation-order accuracy.  A wrong inverse would put values into other minibatches: the offsets
+    make every minibatch's mean different by far more than the tolerance."""
+    from ppo_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    adv = torch.randn(n, device="cuda", generator=gen) * 3.0 + 40.0 + torch.arange(n, device="cuda") * (7.0 / n)
+    for seed, stream in ((5, 0), (2**63 + 11, (3 << 40) + 17)):
+        perm = ops.shuffle_indices(n, seed, stream)
+        got = ops.adv_stats_epoch(adv, seed, stream, batch).cpu().numpy()
+        num_mb = (n + batch - 1) // batch
+        assert got.shape == (num_mb, 3)
+        a64 = adv.double().cpu().numpy()
+        p = perm.cpu().numpy()
+        for m in range(num_mb):
+            idx = perm[m * batch:(m + 1) * batch].contiguous()
+            ref = ops.adv_stats(adv, idx).cpu().numpy()
+            x = a64[p[m * batch:(m + 1) * batch]]
+            assert got[m, 0] == ref[0] == len(x)
+            assert abs(got[m, 1] - ref[1]) <= 1e-12 * abs(ref[1]) and abs(got[m, 1] - x.mean()) <= 1e-11 * abs(x.mean())
+            m2 = ((x - x.mean()) ** 2).sum()
+            assert abs(got[m, 2] - ref[2]) <= 1e-9 * max(ref[2], 1e-30) and abs(got[m, 2] - m2) <= 1e-9 * max(m2, 1e-30)
+        again = ops.adv_stats_epoch(adv, seed, stream, batch).cpu().numpy()
+        assert (again == got).all()                              # fixed summation order
+
+
+def test_epoch_advantage_statistics_argument_checks():
+    from ppo_amd import _lib
+    lib = _lib.load()
+    adv = torch.randn(1024, device="cuda")
+    out = torch.empty((8, 3), dtype=torch.float64, device="cuda")
+    ws = torch.empty(lib.ppo_adv_stats_epoch_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    call = lambda n=1024, batch=256, ws_bytes=ws.numel(), o=out.data_ptr(): lib.ppo_adv_stats_epoch(
+        adv.data_ptr(), n, 1, 2, batch, o, ws.data_ptr(), ws_bytes, None)
+    assert call() == 0
+    for bad in (dict(n=0), dict(batch=0), dict(batch=100), dict(ws_bytes=64), dict(o=None)):   # batch 100: 11 minibatches > 8
+        assert call(**bad) == 1, bad
+    torch.cuda.synchronize()
