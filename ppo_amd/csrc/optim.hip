@@ -76,6 +76,65 @@ __global__ void __launch_bounds__(ADAM_BLOCK) k_clip_adam(AdamArgs a)
     }
 }
 
+
+// The same step with ONE memory round trip, for groups of up to ADAM_SLOTS 1024-element chunks (the dense
+// agents: 11 chunks): a chunk never straddles tensors, so its three pointers are wave-uniform; every
+// thread requests the gradient, moments and parameter of its element of every chunk before anything is
+// used, the block adds the squares, and the update runs from registers.  The generic kernel above walks
+// memory three dependent times (norm pass, then load / store per 1024 elements): 15 us against 6.
+constexpr int ADAM_SLOTS = 16;
+struct AdamSlots {
+    float *p[ADAM_SLOTS], *m[ADAM_SLOTS], *v[ADAM_SLOTS], *g[ADAM_SLOTS];   // already offset to the chunk
+    int cnt[ADAM_SLOTS];
+    int nslots;
+    float max_norm, beta2, w1, w2, eps, step_size, bc2_sqrt;
+};
+
+__global__ void __launch_bounds__(ADAM_BLOCK) k_clip_adam_slots(AdamSlots a)
+{
+    __shared__ double part[ADAM_BLOCK / PPO_WAVE];
+    __shared__ float s_coef;
+    const int tid = threadIdx.x;
+    float g[ADAM_SLOTS], m[ADAM_SLOTS], v[ADAM_SLOTS], p[ADAM_SLOTS];
+#pragma unroll
+    for (int s = 0; s < ADAM_SLOTS; ++s) {
+        const bool on = s < a.nslots && tid < a.cnt[s];
+        g[s] = on ? a.g[s][tid] : 0.0f;
+        m[s] = on ? a.m[s][tid] : 0.0f;
+        v[s] = on ? a.v[s][tid] : 0.0f;
+        p[s] = on ? a.p[s][tid] : 0.0f;
+    }
+    float coef = 1.0f;
+    if (a.max_norm >= 0.0f) {
+        double sq = 0.0;
+#pragma unroll
+        for (int s = 0; s < ADAM_SLOTS; ++s) sq += (double)g[s] * (double)g[s];
+        sq = wave_sum(sq);
+        if ((tid & (PPO_WAVE - 1)) == 0) part[tid / PPO_WAVE] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < ADAM_BLOCK / PPO_WAVE; ++w) t += part[w];
+            s_coef = fminf(a.max_norm / ((float)sqrt(t) + 1e-6f), 1.0f);
+        }
+        __syncthreads();
+        coef = s_coef;
+    }
+#pragma unroll
+    for (int s = 0; s < ADAM_SLOTS; ++s) {
+        if (s < a.nslots && tid < a.cnt[s]) {
+            const float gs = g[s] * coef;
+            const float ms = m[s] + a.w1 * (gs - m[s]);
+            const float vs = a.beta2 * v[s] + a.w2 * (gs * gs);
+            const float denom = sqrtf(vs) / a.bc2_sqrt + a.eps;
+            a.g[s][tid] = gs;
+            a.m[s][tid] = ms;
+            a.v[s][tid] = vs;
+            a.p[s][tid] = p[s] - a.step_size * (ms / denom);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ppo_clip_adam_step(int n_tensors, float *const *params, float *const *exp_avg,
@@ -101,6 +160,27 @@ extern "C" int ppo_clip_adam_step(int n_tensors, float *const *params, float *co
     a.beta2 = (float)beta2; a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2); a.eps = (float)eps;
     a.step_size = (float)(lr / (1.0 - std::pow(beta1, (double)step)));
     a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, (double)step));
-    hipLaunchKernelGGL(k_clip_adam, dim3(1), dim3(ADAM_BLOCK), 0, (hipStream_t)stream, a);
+    // chunks of 1024 elements that stay inside one tensor; few enough of them: the one-round-trip kernel
+    AdamSlots sl{};
+    int ns = 0;
+    long begin = 0;
+    for (int k = 0; k < n_tensors && ns <= ADAM_SLOTS; ++k) {
+        for (long j = 0; j < numel[k]; j += ADAM_BLOCK) {
+            if (ns < ADAM_SLOTS) {
+                sl.p[ns] = params[k] + j; sl.m[ns] = exp_avg[k] + j; sl.v[ns] = exp_avg_sq[k] + j; sl.g[ns] = grads + begin + j;
+                sl.cnt[ns] = (int)(numel[k] - j < ADAM_BLOCK ? numel[k] - j : ADAM_BLOCK);
+            }
+            if (++ns > ADAM_SLOTS) break;
+        }
+        begin += numel[k];
+    }
+    if (ns <= ADAM_SLOTS) {
+        sl.nslots = ns;
+        sl.max_norm = a.max_norm; sl.beta2 = a.beta2; sl.w1 = a.w1; sl.w2 = a.w2; sl.eps = a.eps;
+        sl.step_size = a.step_size; sl.bc2_sqrt = a.bc2_sqrt;
+        hipLaunchKernelGGL(k_clip_adam_slots, dim3(1), dim3(ADAM_BLOCK), 0, (hipStream_t)stream, sl);
+    } else {
+        hipLaunchKernelGGL(k_clip_adam, dim3(1), dim3(ADAM_BLOCK), 0, (hipStream_t)stream, a);
+    }
     return ppo_launch_status();
 }

@@ -170,3 +170,32 @@ def test_trainer_with_fused_optimizer_follows_torch_adam(joint):
     # (an action that flips on a 1e-7 difference in a logit sends that env down another trajectory: allowed for < 1 %)
     for k in (2, 3):
         assert ((runs[True][k] - runs[False][k]).abs() > 2e-4).float().mean() < 0.01
+
+
+def test_clip_adam_large_group_takes_the_generic_kernel():
+    """More than 16 chunks of 1024 elements: the strided kernel instead of the one-round-trip one; same numbers."""
+    import ctypes as C
+    from ppo_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    sizes = [20000, 3, 1025]
+    p = [torch.randn(n, device="cuda", generator=gen) for n in sizes]
+    q = [torch.nn.Parameter(t.clone()) for t in p]
+    m = [torch.zeros_like(t) for t in p]
+    v = [torch.zeros_like(t) for t in p]
+    opt = torch.optim.Adam(q, lr=1e-3, eps=1e-5)
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    numel = (C.c_long * len(sizes))(*sizes)
+    for step in range(1, 4):
+        g = torch.randn(sum(sizes), device="cuda", generator=gen)
+        at = 0
+        for t in q:
+            t.grad = g[at:at + t.numel()].clone()
+            at += t.numel()
+        assert lib.ppo_clip_adam_step(len(sizes), arr(p), arr(m), arr(v), numel, g.data_ptr(), 0.5, 1e-3, 0.9, 0.999, 1e-5,
+                                      step, None) == 0
+        torch.nn.utils.clip_grad_norm_(q, 0.5)
+        opt.step()
+        assert torch.allclose(g, torch.cat([t.grad for t in q]), rtol=1e-5, atol=1e-30)
+    for a, b in zip(p, q):
+        assert torch.allclose(a, b, rtol=0, atol=1e-6)
