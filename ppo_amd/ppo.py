@@ -723,15 +723,17 @@ class PPO:
         rollout_time = ppo_dist.max_scalar(time.time() - rollout_start)   # the job waits for its slowest rank
         env_steps_per_sec = steps_per_env * num_envs * world / rollout_time
 
+        updates_start = time.time()
+        data_size = steps_per_env * num_envs
+        # the first epoch's shuffle goes to the (idle) device before the host-side bookkeeping below
+        first_perm = self._epoch_permutation(data_size, ve.states.device)
         states = ve.states.detach().flatten(0, 1)  # no gradient wrt observations is ever used
         actions = ve.actions.flatten(0, 1)
         log_probs = ve.log_probs.flatten(0, 1)
         values = ve.values.flatten(0, 1)
         advantages = advantages.flatten(0, 1)
-        data_size = steps_per_env * num_envs
         dev = states.device
 
-        updates_start = time.time()
         early = torch.zeros((), dtype=torch.bool, device=dev) if target_div is not None else None
         clip_terms = []                                        # clip_frac of every minibatch, summed once at the end
         grad_steps_done = 0
@@ -756,7 +758,7 @@ class PPO:
         out_rows = (torch.empty((num_epochs * ((data_size + local_batch - 1) // local_batch), 5), dtype=torch.float32,
                                 device=dev) if fused_update else None)
         for _epoch in range(num_epochs):
-            perm = self._epoch_permutation(data_size, dev)     # reference :575-576 (np.random.shuffle)
+            perm = first_perm if _epoch == 0 else self._epoch_permutation(data_size, dev)   # reference :575-576 (np.random.shuffle)
             # the advantage statistics of all of the epoch's minibatches from one streaming pass (the device
             # shuffle's bijection run backwards) instead of one gather per minibatch
             epoch_stats = None
