@@ -147,9 +147,10 @@ def cpu_gae_loss_baseline(T, N, seed):
             "torch_threads": torch.get_num_threads()}
 
 
-def train_step_rates(kind, N, T, world, seed, updates=4):
+def train_step_rates(kind, N, T, world, seed, updates=12, skip=4):
     """The reference's own bracket: PPO.train_step at this workload (global num_envs = N * world,
-    one epoch of four minibatches), joint and split networks; medians over the updates after the first."""
+    one epoch of four minibatches), joint and split networks; medians over the updates after the first `skip`
+    (an update is ~3 ms: the first few sit on the clock ramp of DESIGN.md 7 like the hot loop's warm-up steps)."""
     from ppo_amd import PPO
     from ppo_amd.envs import DeviceEnv
     out = {}
@@ -168,7 +169,7 @@ def train_step_rates(kind, N, T, world, seed, updates=4):
         ppo.train(lambda: DeviceEnv(kind), num_updates=updates, num_envs=N * world, steps_per_env=T, num_epochs=1,
                   batch_size=T * N * world // 4, critic_coef=0.5, entropy_coef=0.01, clip_ratio=0.2, max_grad_norm=0.5,
                   learning_rate=3e-4)
-        med = lambda key: float(np.median([m[key] for m in rows[1:]]))
+        med = lambda key: float(np.median([m[key] for m in rows[skip:]]))
         out[name] = {"train_step_env_steps_per_sec": med("utils/env_steps_per_sec"),
                      "grad_steps_per_sec": med("utils/grad_steps_per_sec"),
                      "global_steps_per_sec": med("utils/global_steps_per_sec"),
@@ -176,9 +177,10 @@ def train_step_rates(kind, N, T, world, seed, updates=4):
         ppo.vec_env.close()
         del ppo
         torch.cuda.empty_cache()
-    out["config"] = (f"{updates} updates, medians of the last {updates - 1}; num_epochs 1, batch_size T*N/4 (global), norm_adv 1, "
+    out["config"] = (f"{updates} updates, medians of the last {updates - skip}; num_epochs 1, batch_size T*N/4 (global), norm_adv 1, "
                      f"clip_va_loss 1; minibatch step = ppo_dense_update_grads (fused forward + loss + backward + weight gradients, net mode of the rollout); "
-                     f"epoch shuffle = ppo_shuffle_indices, minibatch statistics = ppo_adv_stats_gather")
+                     f"epoch shuffle = ppo_shuffle_indices, minibatch statistics = ppo_adv_stats_epoch (one pass per epoch), "
+                     f"clip_grad_norm_ + Adam.step = ppo_clip_adam_step (one launch)")
     return out
 
 
