@@ -364,10 +364,10 @@ def main():
             "mfma_f16_tflops": ro_flops / (ro_ms * 1e-3) / 1e12, "mfma_f16_peak_tflops": MFMA_F16_PEAK_TFLOPS,
             "mfma_frac": ro_flops / (ro_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
             "hbm_write_gbs": ro_bytes / (ro_ms * 1e-3) / 1e9,
-            "note": "neither an HBM- nor an MFMA-bound kernel: by PMC (profiles/r01_rollout_pmc_f16_split.txt) "
-                    "the VALU is active 70 % of the wave cycles (tanh, operand splits, heads, f64 physics, "
-                    "Philox), the 60 f16 MFMAs per wave and step are busy 21 %; event pair around the launch in a "
-                    "back-to-back loop after the timed region, median of 6"}
+            "note": "neither an HBM- nor an MFMA-bound kernel: by PMC (profiles/r02_rollout_pmc_f16_split.txt) "
+                    "the VALU is active 71 % of the wave cycles (1035 instructions per wave and step: tanh, operand "
+                    "splits, heads, f64 physics, Philox), the 60 f16 MFMAs per wave and step are busy 25 %; event pair "
+                    "around the launch in a back-to-back loop after the timed region, median of 6"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, args.cpu_sample_envs, T, args.seed)
             line["cpu_baseline"].update(cpu_gae_loss_baseline(T, N, args.seed))
