@@ -364,6 +364,11 @@ def main():
             "mfma_f16_tflops": ro_flops / (ro_ms * 1e-3) / 1e12, "mfma_f16_peak_tflops": MFMA_F16_PEAK_TFLOPS,
             "mfma_frac": ro_flops / (ro_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
             "hbm_write_gbs": ro_bytes / (ro_ms * 1e-3) / 1e9,
+            # VALU issue: instructions per wave and step from the committed PMC summary (SQ_INSTS_VALU / waves / T,
+            # CartPole joint, 64-env waves) against one wave64 instruction per SIMD every four cycles at 2.4 GHz
+            "valu_insts_per_wave_step": (1035 if (kind == "cartpole" and N > 32768) else None),
+            "valu_issue_frac": ((1035 * waves * T / (ro_ms * 1e-3)) / (1024 * 2.4e9 / 4)
+                                if (kind == "cartpole" and N > 32768) else None),
             "note": "neither an HBM- nor an MFMA-bound kernel: by PMC (profiles/r02_rollout_pmc_f16_split.txt) "
                     "the VALU is active 71 % of the wave cycles (1035 instructions per wave and step: tanh, operand "
                     "splits, heads, f64 physics, Philox), the 60 f16 MFMAs per wave and step are busy 25 %; event pair "
