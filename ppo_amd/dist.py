@@ -118,6 +118,18 @@ def merged_adv_stats(stats3: torch.Tensor) -> torch.Tensor:
     return merge_stats([(g[0], g[1], g[2]) for g in rows])
 
 
+def merged_adv_stats_epoch(stats: torch.Tensor) -> torch.Tensor:
+    """merged_adv_stats for the [num_mb, 3] table of ops.adv_stats_epoch: the statistics of ALL of an epoch's
+    minibatches merged over ranks in ONE collective instead of one per minibatch (same merge, element by element)."""
+    if not is_dist():
+        return stats
+    rows = stats.new_zeros((world_size(),) + tuple(stats.shape))
+    rows[rank()] = stats
+    _all_reduce(rows)
+    from .ops import merge_stats
+    return merge_stats([(g[:, 0], g[:, 1], g[:, 2]) for g in rows]).t().contiguous()
+
+
 def mean_scalar(x: torch.Tensor) -> torch.Tensor:
     if not is_dist():
         return x

@@ -765,6 +765,8 @@ class PPO:
             if (fused_update and self.norm_adv and self._last_perm_keys is not None and self.fused_epoch_stats
                     and (data_size + local_batch - 1) // local_batch <= ops.ADV_STATS_EPOCH_MAX_MB):
                 epoch_stats = ops.adv_stats_epoch(advantages, *self._last_perm_keys, local_batch)
+                if world > 1:                                  # minibatch normalisation stays global: one collective per epoch
+                    epoch_stats = ppo_dist.merged_adv_stats_epoch(epoch_stats)
             for start in range(0, data_size, local_batch):
                 idx = perm[start:start + local_batch]          # last minibatch may be short (:581)
                 if fused_update:                               # the update kernel gathers as it goes
@@ -777,13 +779,14 @@ class PPO:
                     mb_log_probs, mb_values, mb_adv = log_probs[idx], values[idx], advantages[idx]
                 stats3 = None
                 local3 = epoch_stats[start // local_batch] if epoch_stats is not None else None
-                if self.norm_adv and world > 1:                # keep minibatch normalisation global
+                if local3 is not None:
+                    stats3 = local3                            # (already merged over ranks)
+                elif self.norm_adv and world > 1:              # keep minibatch normalisation global
                     stats3 = ppo_dist.merged_adv_stats(
-                        local3 if local3 is not None else
-                        (ops.adv_stats(advantages, idx) if fused_update else ops.adv_stats(mb_adv)))
+                        ops.adv_stats(advantages, idx) if fused_update else ops.adv_stats(mb_adv))
                 if fused_update:
                     if self.norm_adv and stats3 is None:
-                        stats3 = local3 if local3 is not None else ops.adv_stats(advantages, idx)
+                        stats3 = ops.adv_stats(advantages, idx)
                     out5, groups = ops.dense_update_grads(
                         self.agent, states, actions, log_probs, values, advantages, clip_ratio, self.norm_adv,
                         self.clip_va_loss, c_pi=lr_anneal, c_v=critic_coef * lr_anneal, c_ent=entropy_coef * lr_anneal,

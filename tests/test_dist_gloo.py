@@ -41,6 +41,15 @@ def _worker(rank, world, port, out):
                          ((mine - mine.mean()) ** 2).sum()])
     merged = D.merged_adv_stats(stats)
     kl = D.mean_scalar(torch.tensor(float(rank)))
+    # the same for a whole epoch's table [num_mb, 3] in one collective: row m must equal the per-minibatch merge
+    table, singles = [], []
+    for m in range(3):
+        part = (full[m * 300:(m + 1) * 300 + 100])[rank::world] * (m + 1.0)
+        st = torch.stack([torch.tensor(float(part.numel()), dtype=torch.float64), part.mean(), ((part - part.mean()) ** 2).sum()])
+        table.append(st)
+        singles.append(D.merged_adv_stats(st))
+    epoch = D.merged_adv_stats_epoch(torch.stack(table))
+    assert epoch.shape == (3, 3) and epoch.is_contiguous() and torch.equal(epoch, torch.stack(singles))
     out[rank] = dict(flat=flat, local=local, avg=avg, merged=merged, kl=kl,
                      want=torch.stack([torch.tensor(1000.0, dtype=torch.float64), full.mean(),
                                        ((full - full.mean()) ** 2).sum()]))
@@ -67,6 +76,8 @@ def test_single_process_is_identity():
     assert D.world_size() == 1 and D.rank() == 0 and not D.is_dist()
     s = torch.tensor([3.0, 1.0, 2.0], dtype=torch.float64)
     assert D.merged_adv_stats(s) is s and D.mean_scalar(s) is s
+    t = torch.zeros((4, 3), dtype=torch.float64)
+    assert D.merged_adv_stats_epoch(t) is t
     assert D.init_from_env() is False or "RANK" in os.environ
 
 
