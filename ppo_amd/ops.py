@@ -26,7 +26,8 @@ def device() -> torch.device:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # torch.cuda.current_stream().cuda_stream by its two C calls (the Python wrapper objects cost ~9 us per launch)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
@@ -474,7 +475,7 @@ def dense_update_supported(agent) -> bool:
 
 
 def dense_update_grads(agent, states, actions, old_log_probs, old_values, advantages, clip_ratio, norm_adv, clip_va_loss,
-                       c_pi, c_v, c_ent, stats3=None, idx=None, net_mode: int = NET_F32, out5=None):
+                       c_pi, c_v, c_ent, stats3=None, idx=None, net_mode: int = NET_F32, out5=None, reuse_bucket=False):
     """ppo_dense_update_grads for a ppo_amd Agent: one launch per backbone.
     Returns (out5, groups): out5 = device f32[5] {policy_loss, value_loss, clip_frac, kl_div, entropy};
     groups = one list of (parameter, gradient tensor) per launch -- [all parameters] for a joint network,
@@ -483,7 +484,10 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
     idx (int64 [B], optional): the minibatch is rows idx of the given (flattened rollout) tensors -- the kernel
     gathers as it goes (reference src/ppo.py:582-588); the advantage statistics are those of the minibatch.
     net_mode: NET_F32, or NET_F16_SPLIT for parameter sets inside the split mode's limits (split_ok).
-    out5: where to write out5 (device f32[5], e.g. a row of a per-update table) instead of a new tensor."""
+    out5: where to write out5 (device f32[5], e.g. a row of a per-update table) instead of a new tensor.
+    reuse_bucket: write the gradients into ONE bucket per (agent, heads) that every such call reuses (the views
+    into it are built once; the trainer's loop, where the optimiser step consumes a launch's gradients before the
+    next launch is queued) instead of a fresh buffer per call."""
     lib = _lib.load()
     assert net_mode in (NET_F32, NET_F16_SPLIT)
     dev = states.device
@@ -504,30 +508,36 @@ def dense_update_grads(agent, states, actions, old_log_probs, old_values, advant
         out5 = torch.empty(5, dtype=torch.float32, device=dev)
     assert out5.is_cuda and out5.dtype == torch.float32 and out5.is_contiguous() and out5.numel() == 5
     groups = []
+    cache = agent.__dict__.setdefault("_ppo_grad_buckets", {})
 
     def run(backbone, heads):
-        pairs = GradGroup()
-        groups.append(pairs)
-        n = lib.ppo_dense_update_grad_floats(obs, A, heads)
-        g = pairs.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        ent = cache.get(heads) if reuse_bucket else None
         l1, l2 = backbone[0], backbone[2]
-        pw, pb = (agent.policy.weight, agent.policy.bias) if heads & 1 else (None, None)
-        cw, cb = (agent.critic.weight, agent.critic.bias) if heads & 2 else (None, None)
-        params = [l1.weight, l1.bias, l2.weight, l2.bias] + ([pw, pb] if heads & 1 else []) + ([cw, cb] if heads & 2 else [])
-        for p in params:
-            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+        if ent is None or ent["w1"] is not l1.weight or ent["dev"] != dev:
+            pw, pb = (agent.policy.weight, agent.policy.bias) if heads & 1 else (None, None)
+            cw, cb = (agent.critic.weight, agent.critic.bias) if heads & 2 else (None, None)
+            params = [l1.weight, l1.bias, l2.weight, l2.bias] + ([pw, pb] if heads & 1 else []) + ([cw, cb] if heads & 2 else [])
+            for p in params:
+                assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+            n = lib.ppo_dense_update_grad_floats(obs, A, heads)
+            pairs = GradGroup()
+            g = pairs.flat = torch.empty(n, dtype=torch.float32, device=dev)
+            at = 0
+            for p in params:
+                pairs.append((p, g[at:at + p.numel()].view_as(p)))
+                at += p.numel()
+            assert at == n
+            ent = {"w1": l1.weight, "dev": dev, "pairs": pairs, "slots": [l1.weight, l1.bias, l2.weight, l2.bias, pw, pb, cw, cb]}
+            if reuse_bucket:
+                cache[heads] = ent
+        pairs = ent["pairs"]
+        groups.append(pairs)
         rc = lib.ppo_dense_update_grads(
-            obs, A, heads, int(net_mode), l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(),
-            _ptr(pw), _ptr(pb), _ptr(cw), _ptr(cb), _ptr(idx), states.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr(),
-            old_values.data_ptr(), advantages.data_ptr(), _ptr(stats3), float(clip_ratio), int(bool(norm_adv)),
-            int(bool(clip_va_loss)), B, float(c_pi), float(c_v), float(c_ent), out5.data_ptr(), g.data_ptr(),
-            ws.data_ptr(), ws.numel(), _stream())
+            obs, A, heads, int(net_mode), *[_ptr(t) for t in ent["slots"]], _ptr(idx), states.data_ptr(), actions.data_ptr(),
+            old_log_probs.data_ptr(), old_values.data_ptr(), advantages.data_ptr(), _ptr(stats3), float(clip_ratio),
+            int(bool(norm_adv)), int(bool(clip_va_loss)), B, float(c_pi), float(c_v), float(c_ent), out5.data_ptr(),
+            pairs.flat.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         _lib.check(rc, "ppo_dense_update_grads")
-        at = 0
-        for p in params:
-            pairs.append((p, g[at:at + p.numel()].view_as(p)))
-            at += p.numel()
-        assert at == n
 
     if agent.joint_net:
         run(agent.pi_backbone, 3)
@@ -570,13 +580,19 @@ def clip_adam_step(opt, group: "GradGroup", max_grad_norm: float):
             assert st["step"].device.type == "cpu"
         n = len(params)
         arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        # the group's step counters become views of ONE host tensor: one increment per launch instead of n
+        # (they stay ordinary 0-d tensors for state_dict and for a plain opt.step())
+        steps_all = torch.tensor([float(st["step"]) for st in states], dtype=torch.float32)
+        assert bool((steps_all == steps_all[0]).all()), "the parameters of one group have always been stepped together"
+        for k, st in enumerate(states):
+            st["step"] = steps_all[k]
         ent = cache[key] = {"m": [st["exp_avg"] for st in states], "v": [st["exp_avg_sq"] for st in states],
-                            "steps": [st["step"] for st in states], "n": n,
+                            "steps_all": steps_all, "n": n,
                             "p_arr": arr(params), "numel": (C.c_long * n)(*[p.numel() for p in params])}
         ent["m_arr"], ent["v_arr"] = arr(ent["m"]), arr(ent["v"])
     g = opt.param_groups[0]
-    torch._foreach_add_(ent["steps"], 1)
-    step = int(ent["steps"][0].item())
+    ent["steps_all"] += 1
+    step = int(ent["steps_all"][0])
     flat = group.flat
     assert flat.is_cuda and flat.dtype == torch.float32 and flat.numel() == sum(p.numel() for p in params)
     rc = lib.ppo_clip_adam_step(ent["n"], ent["p_arr"], ent["m_arr"], ent["v_arr"], ent["numel"], flat.data_ptr(),

@@ -790,7 +790,8 @@ class PPO:
                     out5, groups = ops.dense_update_grads(
                         self.agent, states, actions, log_probs, values, advantages, clip_ratio, self.norm_adv,
                         self.clip_va_loss, c_pi=lr_anneal, c_v=critic_coef * lr_anneal, c_ent=entropy_coef * lr_anneal,
-                        stats3=stats3, idx=idx, net_mode=upd_mode, out5=out_rows[grad_steps_done])
+                        stats3=stats3, idx=idx, net_mode=upd_mode, out5=out_rows[grad_steps_done],
+                        reuse_bucket=self.minibatch_hook is None)
                     policy_loss, critic_loss, clip_frac, kl_div, entropy = out5.unbind(0)
                 elif fused_head:   # Categorical log-prob + entropy + ratio + losses in one pass (:186-216, :595-599)
                     logits, new_values = self.agent.policy_and_values(mb_states)
@@ -804,9 +805,11 @@ class PPO:
                         self.norm_adv, self.clip_va_loss, ratio_input=False, stats3=stats3)  # :595-599
                 if fused_update:                               # gradients are already there: :602-625 without backward()
                     for k, (opt, grp) in enumerate(zip((self.pi_optimizer, self.va_optimizer), groups)):
-                        opt.zero_grad()
+                        if not fused_opt:                       # Adam.step skips parameters without a gradient (:614-625)
+                            opt.zero_grad()
                         for prm, grad in grp:
-                            prm.grad = grad
+                            if prm.grad is not grad:
+                                prm.grad = grad
                         ppo_dist.allreduce_flat(grp.flat)       # the group's gradients are views of one bucket
                         if fused_opt:                           # :608-609 as one launch on that bucket
                             ops.clip_adam_step(opt, grp, max_grad_norm)
