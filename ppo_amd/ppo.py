@@ -816,8 +816,8 @@ class PPO:
                         else:
                             nn.utils.clip_grad_norm_(params, max_grad_norm)
                             opt.step()
-                    if not self.joint_network:
-                        critic_loss = critic_coef * critic_loss
+                    if not self.joint_network and self.minibatch_hook is not None:
+                        critic_loss = critic_coef * critic_loss    # (:619; without a hook the logged value is scaled on the host)
                 elif self.joint_network:                       # reference :602-609
                     total = (policy_loss + critic_coef * critic_loss - entropy_coef * entropy) * lr_anneal
                     self.pi_optimizer.zero_grad()
@@ -854,10 +854,15 @@ class PPO:
         diag = ve.prepack() if (ve.native and ve.fused_rollout and dev.type == "cuda") else None
         # one device->host copy for every scalar of this update (it is also the update's final sync)
         # -- together with the rollout's episode statistics and reward sum when those still live on the device
-        clip_sum = torch.stack(clip_terms).sum(dtype=torch.float32).to(dev)
-        scalars = [policy_loss.detach().to(dev), critic_loss.detach().to(dev), entropy.detach().to(dev),
-                   kl_div.detach().to(dev), clip_sum]
-        pieces = [torch.stack([s.to(torch.float32).reshape(()) for s in scalars])]
+        rows_form = fused_update and grad_steps_done > 0
+        if rows_form:       # the update kernel's table: the last minibatch's row as it is + the sum of the clip_frac column
+            pieces = [out_rows[grad_steps_done - 1], out_rows[:grad_steps_done, 2].sum(dtype=torch.float32).reshape(1)]
+        else:
+            clip_sum = torch.stack(clip_terms).sum(dtype=torch.float32).to(dev)
+            scalars = [policy_loss.detach().to(dev), critic_loss.detach().to(dev), entropy.detach().to(dev),
+                       kl_div.detach().to(dev), clip_sum]
+            pieces = [torch.stack([s.to(torch.float32).reshape(()) for s in scalars])]
+        n_own = 6 if rows_form else 5
         if diag is not None:
             pieces.append(diag.to(dev))
         ve_vals, ve_take = ve.pending_device_scalars() if (ve.native and dev.type == "cuda") else (None, None)
@@ -867,9 +872,12 @@ class PPO:
             ve_take = None
         host = (pieces[0] if len(pieces) == 1 else torch.cat(pieces)).cpu().tolist()
         if diag is not None:
-            ve.note_split_diag(host[5:8])
+            ve.note_split_diag(host[n_own:n_own + 3])
         if ve_take is not None:
-            ve_take(host[5 + (3 if diag is not None else 0):])
+            ve_take(host[n_own + (3 if diag is not None else 0):])
+        if rows_form:       # {policy_loss, value_loss, clip_frac, kl_div, entropy} + clip sum -> the order used below
+            scale = 1.0 if self.joint_network else critic_coef          # :619 (the table holds the unscaled value loss)
+            host = [host[0], host[1] * scale, host[4], host[3], host[5]]
         updates_time = ppo_dist.max_scalar(time.time() - updates_start)
         self._idle = dev.type == "cuda" and world == 1
         grad_steps_per_sec = grad_steps_done / updates_time
