@@ -157,3 +157,19 @@ def test_cli_positional_order_matches_reference():
     assert (a.norm_adv, a.clip_va_loss, a.conv_net, a.joint_network, a.use_gpu, a.target_div) == (1, 1, 0, 0, 1, 0.01)
     assert a.render_every == 0 and a.render_fps == 0.0 and a.early_stop_reward is None
     assert callable(ppo_cli.resolve_env_fn("env_acrobot"))
+
+
+def test_clip_adam_supported_is_host_logic():
+    """Which optimisers the one-launch clip + Adam step takes over (the reference's optim.Adam(lr, eps=1e-5),
+    src/ppo.py:732-733) -- decided on the host, no device needed."""
+    import torch
+    from ppo_amd import ops
+    w = torch.nn.Parameter(torch.zeros(4))
+    assert ops.clip_adam_supported(torch.optim.Adam([w], lr=3e-4, eps=1e-5))
+    assert not ops.clip_adam_supported(torch.optim.Adam([w], weight_decay=0.1))
+    assert not ops.clip_adam_supported(torch.optim.Adam([w], amsgrad=True))
+    assert not ops.clip_adam_supported(torch.optim.Adam([w], maximize=True))
+    assert not ops.clip_adam_supported(torch.optim.Adam([w], lr=torch.tensor(1e-3)))
+    assert not ops.clip_adam_supported(torch.optim.Adam([{"params": [w]}, {"params": [torch.nn.Parameter(torch.zeros(2))]}]))
+    assert not ops.clip_adam_supported(torch.optim.AdamW([w]))
+    assert not ops.clip_adam_supported(torch.optim.SGD([w], lr=0.1))
