@@ -569,7 +569,8 @@ def clip_adam_step(opt, group: "GradGroup", max_grad_norm: float):
     cache = opt.__dict__.setdefault("_ppo_clip_adam", {})
     ent = cache.get(key)
     states = [opt.state[p] for p in params]
-    if ent is None or any(st.get("exp_avg") is not m for st, m in zip(states, ent["m"])):
+    ptrs = tuple(p.data_ptr() for p in params)           # (a parameter whose storage moved -- .to(), .data = -- rebuilds the table)
+    if ent is None or ent["pp"] != ptrs or any(st.get("exp_avg") is not m for st, m in zip(states, ent["m"])):
         for p, st in zip(params, states):
             if len(st) == 0:                       # torch/optim/adam.py _init_group
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
@@ -587,7 +588,7 @@ def clip_adam_step(opt, group: "GradGroup", max_grad_norm: float):
         for k, st in enumerate(states):
             st["step"] = steps_all[k]
         ent = cache[key] = {"m": [st["exp_avg"] for st in states], "v": [st["exp_avg_sq"] for st in states],
-                            "steps_all": steps_all, "n": n,
+                            "steps_all": steps_all, "n": n, "pp": ptrs,
                             "p_arr": arr(params), "numel": (C.c_long * n)(*[p.numel() for p in params])}
         ent["m_arr"], ent["v_arr"] = arr(ent["m"]), arr(ent["v"])
     g = opt.param_groups[0]

@@ -112,6 +112,25 @@ def test_clip_adam_state_is_adams_own_state():
                               atol=2e-6 * float(opt_b.state[pb]["exp_avg"].abs().max()))
 
 
+def test_clip_adam_follows_a_parameter_whose_storage_moved():
+    """The cached pointer table is rebuilt when a parameter's storage changes (p.data = ..., module.to()): the step
+    lands in the new storage, the old one is left alone."""
+    from ppo_amd import ops
+    torch.manual_seed(8)
+    a = _agent("cartpole", 1)
+    opt = torch.optim.Adam(a.parameters(), lr=1e-2, eps=1e-5)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    ops.clip_adam_step(opt, _group(a, "joint", gen, 1.0), 0.5)
+    old = a.critic.weight.data
+    a.critic.weight.data = old.clone()
+    snapshot = old.clone()
+    before = a.critic.weight.detach().clone()
+    ops.clip_adam_step(opt, _group(a, "joint", gen, 1.0), 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(old, snapshot)                                    # nothing written through the stale pointer
+    assert (a.critic.weight.detach() - before).abs().max() > 1e-4        # the live parameter took the step
+
+
 def test_clip_adam_rejects_bad_arguments_and_other_optimisers():
     import ctypes as C
     from ppo_amd import _lib, ops
