@@ -719,7 +719,7 @@ class PPO:
             advantages = self._rollout_advantages(ve)
         if ve.native:
             ve._flush_stats()                      # the reference's rollout() ends with the episode statistics (:404-417)
-        _sync()
+        _sync_spin()
         rollout_time = ppo_dist.max_scalar(time.time() - rollout_start)   # the job waits for its slowest rank
         env_steps_per_sec = steps_per_env * num_envs * world / rollout_time
 
@@ -1029,3 +1029,25 @@ class PPO:
 def _sync():
     if torch.cuda.is_available():
         torch.cuda.synchronize()
+
+
+_spin_events = {}          # one per device: an event belongs to the device it was first recorded on
+
+
+def _sync_spin():
+    """_sync() for the end of the rollout bracket: poll an event recorded behind the bracket's last kernel instead of
+    blocking in hipDeviceSynchronize -- the blocked thread is woken ~20 us after the kernel has finished, the poll sees it
+    within a few (the bracket is ~0.5 ms and the host has nothing else to do: src/ppo.py:544-560 blocks there too).
+    PPO_AMD_SPIN_SYNC=0: block."""
+    if not torch.cuda.is_available():
+        return
+    if os.environ.get("PPO_AMD_SPIN_SYNC", "1") == "0":
+        torch.cuda.synchronize()
+        return
+    d = torch.cuda.current_device()
+    ev = _spin_events.get(d)
+    if ev is None:
+        ev = _spin_events[d] = torch.cuda.Event(enable_timing=False, blocking=False)
+    ev.record()                                    # current stream: everything the bracket launched is on it
+    while not ev.query():
+        pass
