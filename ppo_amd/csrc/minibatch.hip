@@ -157,8 +157,10 @@ ShuffleKeys make_shuffle_keys(long n, uint64_t seed, uint64_t stream_id)
 // minibatch inv(j) / batch -- one coalesced pass over adv serves all minibatches of the epoch at once.
 // Each step of shuffle_bijection is inverted exactly: x ^= x >> s by the doubling series, the affine step
 // by the multiplier's inverse modulo 2^k (Newton's iteration on the host); cycle walking works the same
-// way in reverse.  Shifted sums as in loss.hip (K = adv[0]); per-thread f64 accumulators live in LDS
-// ([minibatch][sum, sum of squares][thread]: conflict-free), blocks and threads add in a fixed order.
+// way in reverse.  Branch-free per application (the doubling steps beyond k bits are masked off by host-made masks; the
+// minibatch of a position is a count of compares against host-made bounds).  Shifted sums as in loss.hip (K = adv[0]);
+// per-thread f64 accumulators {sum, sum of squares} live in LDS as one 16-byte word per (minibatch, thread), blocks and
+// threads add in a fixed order.
 constexpr int EPOCH_MAX_MB = 8;
 constexpr int EPOCH_BLOCK = 256;
 constexpr int EPOCH_GRID = 1024;
@@ -166,58 +168,71 @@ constexpr int EPOCH_GRID = 1024;
 struct ShuffleInvKeys {
     uint32_t inv[SHUF_ROUNDS], add[SHUF_ROUNDS];
     uint32_t mask;
-    int sh_a, sh_b, k;
+    int sh_a;                      // 2 sh_a >= k: one step undoes x ^= x >> sh_a
+    int sb[3];                     // sh_b, 2 sh_b, 4 sh_b (clamped to 31): the doubling series of the undo ...
+    uint32_t mb[3];                // ... and all-ones / zero for the steps below / beyond k bits (branch-free)
+    unsigned long long bound[EPOCH_MAX_MB - 1];   // first position of minibatch m + 1 (~0 for minibatches that do not exist)
 };
-
-__device__ __forceinline__ uint32_t undo_xorshift(uint32_t y, int s, int k)
-{
-    for (int t = s; t < k; t <<= 1) y ^= y >> t;
-    return y;
-}
 
 __device__ __forceinline__ uint32_t shuffle_bijection_inv(uint32_t y, const ShuffleInvKeys &q)
 {
-    y = undo_xorshift(y, q.sh_a, q.k);
+    y ^= y >> q.sh_a;
 #pragma unroll
     for (int r = SHUF_ROUNDS - 1; r >= 0; --r) {
         y = ((y - q.add[r]) * q.inv[r]) & q.mask;
-        y = undo_xorshift(y, (r & 1) ? q.sh_b : q.sh_a, q.k);
+        if (r & 1) {
+            y ^= y >> q.sb[0];
+            y ^= (y >> q.sb[1]) & q.mb[1];
+            y ^= (y >> q.sb[2]) & q.mb[2];
+        } else {
+            y ^= y >> q.sh_a;
+        }
     }
     return y;
 }
 
-__global__ void __launch_bounds__(EPOCH_BLOCK) k_adv_stats_epoch(ShuffleInvKeys q, const float *adv, long n, long batch,
-                                                                  int num_mb, double *partials)
+__global__ void __launch_bounds__(EPOCH_BLOCK) k_adv_stats_epoch(ShuffleInvKeys q, const float *adv, long n, int num_mb,
+                                                                  double *partials)
 {
-    __shared__ double slot[EPOCH_MAX_MB * 2][EPOCH_BLOCK];
+    // per-thread accumulators {sum, sum of squares} of every minibatch: one 16-byte LDS word each
+    __shared__ double2 slot[EPOCH_MAX_MB][EPOCH_BLOCK];
     const int tid = threadIdx.x;
-    for (int c = 0; c < num_mb * 2; ++c) slot[c][tid] = 0.0;
+    for (int c = 0; c < num_mb; ++c) slot[c][tid] = make_double2(0.0, 0.0);
     const double K = (double)adv[0];
     const long stride = (long)gridDim.x * EPOCH_BLOCK;
     for (long j0 = (long)blockIdx.x * EPOCH_BLOCK + tid; j0 < n; j0 += 4 * stride) {
         float e[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) e[u] = j0 + u * stride < n ? adv[j0 + u * stride] : 0.0f;
+        int mb[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long j = j0 + u * stride;
-            if (j < n) {
-                uint32_t x = (uint32_t)j;
-                do x = shuffle_bijection_inv(x, q);
-                while ((long)x >= n);                  // cycle walking, backwards
-                int mb = 0;
-                for (int m = 1; m < num_mb; ++m) mb += (long)x >= m * batch;
+            uint32_t x = (uint32_t)(j < n ? j : 0);
+            do x = shuffle_bijection_inv(x, q);
+            while ((long)x >= n);                      // cycle walking, backwards
+            int m = 0;
+#pragma unroll
+            for (int b = 0; b < EPOCH_MAX_MB - 1; ++b) m += (unsigned long long)x >= q.bound[b];
+            mb[u] = j < n ? m : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (mb[u] >= 0) {
                 const double d = (double)e[u] - K;
-                slot[2 * mb][tid] += d;
-                slot[2 * mb + 1][tid] += d * d;
+                double2 s = slot[mb[u]][tid];
+                s.x += d;
+                s.y += d * d;
+                slot[mb[u]][tid] = s;
             }
         }
     }
     // this block's sums: every wave reduces its threads' slots, thread 0 adds the waves in order
     __shared__ double part[EPOCH_BLOCK / PPO_WAVE][EPOCH_MAX_MB * 2];
-    for (int c = 0; c < num_mb * 2; ++c) {
-        const double w = wave_sum(slot[c][tid]);
-        if ((tid & (PPO_WAVE - 1)) == 0) part[tid / PPO_WAVE][c] = w;
+    for (int c = 0; c < num_mb; ++c) {
+        const double2 s = slot[c][tid];
+        const double w0 = wave_sum(s.x), w1 = wave_sum(s.y);
+        if ((tid & (PPO_WAVE - 1)) == 0) { part[tid / PPO_WAVE][2 * c] = w0; part[tid / PPO_WAVE][2 * c + 1] = w1; }
     }
     __syncthreads();
     if (tid < num_mb * 2) {
@@ -230,18 +245,25 @@ __global__ void __launch_bounds__(EPOCH_BLOCK) k_adv_stats_epoch(ShuffleInvKeys 
 __global__ void __launch_bounds__(EPOCH_BLOCK) k_adv_stats_epoch_final(const float *adv, long n, long batch, int num_mb,
                                                                         const double *partials, int nblocks, double *stats3)
 {
-    __shared__ double part[EPOCH_BLOCK / PPO_WAVE][EPOCH_MAX_MB * 2];
-    const int tid = threadIdx.x;
-    for (int c = 0; c < num_mb * 2; ++c) {
-        double a = 0.0;
-        for (int b = tid; b < nblocks; b += EPOCH_BLOCK) a += partials[(size_t)b * (EPOCH_MAX_MB * 2) + c];
-        a = wave_sum(a);
-        if ((tid & (PPO_WAVE - 1)) == 0) part[tid / PPO_WAVE][c] = a;
+    // thread = (row group g, column c): column c of the rows g, g + 16, ... (coalesced: 16 consecutive doubles per row),
+    // then the 16 groups are added in order
+    constexpr int NC = EPOCH_MAX_MB * 2, NG = EPOCH_BLOCK / NC;
+    __shared__ double part[NG][NC];
+    const int tid = threadIdx.x, c = tid % NC, g = tid / NC;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;                 // four independent chains: loads in flight
+    int b = g;
+    for (; b + 3 * NG < nblocks; b += 4 * NG) {
+        a0 += partials[(size_t)b * NC + c];
+        a1 += partials[(size_t)(b + NG) * NC + c];
+        a2 += partials[(size_t)(b + 2 * NG) * NC + c];
+        a3 += partials[(size_t)(b + 3 * NG) * NC + c];
     }
+    for (; b < nblocks; b += NG) a0 += partials[(size_t)b * NC + c];
+    part[g][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (tid < num_mb) {
         double S = 0.0, Q = 0.0;
-        for (int w = 0; w < EPOCH_BLOCK / PPO_WAVE; ++w) { S += part[w][2 * tid]; Q += part[w][2 * tid + 1]; }
+        for (int w = 0; w < NG; ++w) { S += part[w][2 * tid]; Q += part[w][2 * tid + 1]; }
         const long lo = tid * batch, hi = lo + batch < n ? lo + batch : n;
         const double cnt = (double)(hi - lo), K = (double)adv[0];
         stats3[3 * tid + 0] = cnt;
@@ -322,20 +344,28 @@ int ppo_adv_stats_epoch(const float *adv, long n, uint64_t seed, uint64_t stream
     PPO_REQUIRE(workspace_bytes >= ppo_adv_stats_epoch_workspace_bytes());
     const ShuffleKeys f = make_shuffle_keys(n, seed, stream_id);
     ShuffleInvKeys q;
-    q.mask = f.mask; q.sh_a = f.sh_a; q.sh_b = f.sh_b;
-    q.k = 2;
-    while (q.k < 32 && (1L << q.k) < n) ++q.k;
+    q.mask = f.mask; q.sh_a = f.sh_a;
+    int k = 2;
+    while (k < 32 && (1L << k) < n) ++k;
+    for (int i = 0; i < 3; ++i) {
+        const int t = f.sh_b << i;
+        q.sb[i] = t < 31 ? t : 31;
+        q.mb[i] = t < k ? 0xFFFFFFFFu : 0u;
+    }
+    PPO_REQUIRE((f.sh_b << 3) >= k && 2 * f.sh_a >= k);   // three doubling steps (one for sh_a) undo the xorshifts for every k <= 32
     for (int r = 0; r < SHUF_ROUNDS; ++r) {
         uint32_t inv = f.mul[r];                               // odd a: a * a = 1 mod 8, each Newton step doubles the bits
         for (int it = 0; it < 5; ++it) inv *= 2u - f.mul[r] * inv;
         q.inv[r] = inv;
         q.add[r] = f.add[r];
     }
+    for (int m = 0; m < EPOCH_MAX_MB - 1; ++m)
+        q.bound[m] = m + 1 < num_mb ? (unsigned long long)(m + 1) * (unsigned long long)batch : ~0ull;
     long blocks = (n + EPOCH_BLOCK * 4 - 1) / (EPOCH_BLOCK * 4);
     if (blocks > EPOCH_GRID) blocks = EPOCH_GRID;
     hipStream_t s = (hipStream_t)stream;
     double *partials = static_cast<double *>(workspace);
-    hipLaunchKernelGGL(k_adv_stats_epoch, dim3((unsigned)blocks), dim3(EPOCH_BLOCK), 0, s, q, adv, n, batch, (int)num_mb, partials);
+    hipLaunchKernelGGL(k_adv_stats_epoch, dim3((unsigned)blocks), dim3(EPOCH_BLOCK), 0, s, q, adv, n, (int)num_mb, partials);
     int rc = ppo_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(k_adv_stats_epoch_final, dim3(1), dim3(EPOCH_BLOCK), 0, s, adv, n, batch, (int)num_mb,
