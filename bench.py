@@ -81,6 +81,11 @@ def parse():
                    help="time every K-th GAE dispatch of the timed region with a start/stop event pair (0: none)")
     p.add_argument("--cpu-sample-envs", type=int, default=4096)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--sustained-seconds", type=float, default=2.0,
+                   help="after the timed region: this many seconds of back-to-back steps, reported beside `value` "
+                        "(clocks / thermals over seconds; something for a busy sampler to see); 0 = skip")
+    p.add_argument("--dry", action="store_true",
+                   help="plumbing only: launch / rendezvous / count the ranks, no GPU work (runs on a CPU box over gloo)")
     return p.parse_args()
 
 
@@ -151,7 +156,7 @@ def train_step_rates(kind, N, T, world, seed, updates=12, skip=4):
     """The reference's own bracket: PPO.train_step at this workload (global num_envs = N * world,
     one epoch of four minibatches), joint and split networks; medians over the updates after the first `skip`
     (an update is ~3 ms: the first few sit on the clock ramp of DESIGN.md 7 like the hot loop's warm-up steps)."""
-    from ppo_amd import PPO
+    from ppo_amd import PPO, ops
     from ppo_amd.envs import DeviceEnv
     out = {}
     for name, joint in (("joint", 1), ("split", 0)):
@@ -173,7 +178,7 @@ def train_step_rates(kind, N, T, world, seed, updates=12, skip=4):
         out[name] = {"train_step_env_steps_per_sec": med("utils/env_steps_per_sec"),
                      "grad_steps_per_sec": med("utils/grad_steps_per_sec"),
                      "global_steps_per_sec": med("utils/global_steps_per_sec"),
-                     "net_mode_used": {0: "f32", 1: "f16_split"}[ppo.vec_env.net_mode_used]}
+                     "net_mode_used": ops.NET_NAMES[ppo.vec_env.net_mode_used]}
         ppo.vec_env.close()
         del ppo
         torch.cuda.empty_cache()
@@ -189,22 +194,38 @@ def main():
     if os.environ.get("PPO_AMD_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["PPO_AMD_BENCH_WATCHDOG"]), exit=True)
-    from ppo_amd import PPO, Agent, SyncVecEnv, ops, _lib
-    lib = _lib.load()
-    from ppo_amd import dist as D
-    from ppo_amd.envs import DeviceEnv
-
+    from ppo_amd import launch
+    backend = os.environ.get("PPO_AMD_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on a 1-GPU box
+    if launch.needs_self_launch(args.gpus):
+        # `python bench.py --gpus N` as ONE plain process: become N ranks.  The parent starts them BEFORE any GPU
+        # call of its own, relays their output (inherited stdout) and exits with the first non-zero child status.
+        if not args.dry:
+            launch.check_gpu_count(args.gpus, backend, f"bench.py --gpus {args.gpus}")
+        sys.exit(launch.self_launch(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    from ppo_amd import dist as D
+    if args.dry:
+        return dry_run(args, D, world, rank)
+    from ppo_amd import PPO, Agent, SyncVecEnv, ops, _lib
+    lib = _lib.load()
+    from ppo_amd.envs import DeviceEnv
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: ppo_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    backend = os.environ.get("PPO_AMD_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on a 1-GPU box
     if world > 1:
-        D.init_from_env(backend)
+        D.init_from_env(backend)            # RCCL: LOCAL_RANK must name a GPU of its own (raises otherwise)
+    else:
+        torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    # proof that the collective backend saw every rank, and where each one sits
+    ranks_seen = int(D.sum_tensor(torch.ones(1, dtype=torch.float32, device=dev if backend == "nccl" or world == 1 else "cpu"),
+                                  "ranks_seen").item())
+    devices = D.gather_rows(torch.tensor([float(dev.index)], device=dev if backend == "nccl" or world == 1 else "cpu"),
+                            "rank_devices").reshape(-1).int().tolist()
 
     N, T, kind = args.num_envs, args.rollout_len, args.env
     torch.manual_seed(args.seed + rank)
@@ -241,9 +262,8 @@ def main():
         return adv
 
     def barrier():
-        if world > 1:
-            torch.distributed.barrier()
         torch.cuda.synchronize()
+        D.barrier("bench_barrier")
 
     def timed_steps(record):
         for _ in range(args.warmup):
@@ -269,54 +289,80 @@ def main():
     for _ in range(args.settle_steps):
         hot_path_step(False)
     elapsed = timed_steps(True)
-    mode_used = {ops.NET_F32: "f32", ops.NET_F16_SPLIT: "f16_split"}[ve.net_mode_used]
+    mode_used = ops.NET_NAMES[ve.net_mode_used]
+
     def max_over_ranks(x):
-        if world > 1:
-            t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            return float(t.item())
-        return x
+        return D.max_scalar(x, "bench_time_max")
 
     elapsed = max_over_ranks(elapsed)
     elapsed_idle = max_over_ranks(elapsed_idle)
-    # The same K steps once more with the network's products done as exact f32 FMAs (PPO_NET_F32)
-    # instead of the default two-piece f16 splits, reported beside `value` as the conservative figure.
-    ve.net_mode = ops.NET_F32
-    for _ in range(2):
-        hot_path_step(False)
-    ve._flush_stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hot_path_step(False)
-    ve._flush_stats()
-    barrier()
-    elapsed_f32 = max_over_ranks(time.perf_counter() - t0)
-    ve.net_mode = ops.NET_AUTO
 
-    # The rollout kernel alone (it is ~85 % of a step): a few more rollouts with an event pair around
-    # the launch, outside the timed region -- an event pair inside it would add barrier packets.
-    pairs = []
-    for _ in range(8):                             # back to back like the timed steps (an idle GPU clocks higher)
-        ve._flush_stats()                          # the previous rollout's statistics kernels stay outside the pair
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ve.rollout()
-        e1.record()
-        pairs.append((e0, e1))
-        ops.gae_dense(ve.rewards, ve.values, ve._ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95)
+    def forced_mode_steps(mode):
+        """The same K steps with the network arithmetic forced to `mode`."""
+        ve.net_mode = mode
+        for _ in range(2):
+            hot_path_step(False)
+        ve._flush_stats()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hot_path_step(False)
+        ve._flush_stats()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        ve.net_mode = ops.NET_AUTO
+        return dt
+
+    # Beside `value` (the library's default: two-piece f16 splits where they measure as accurate as f32): the same
+    # steps at the reference's arithmetic.  PPO_NET_BF16X3: operands represented exactly in three bf16 pieces, the
+    # six largest cross terms of every product in one f32 accumulator -- as accurate as the exact-f32 kernels at
+    # every weight scale (tests/test_gpu_net_precision.py), and what `auto` runs outside the f16 split's limits.
+    # PPO_NET_F32: every product an exact f32 FMA on the f32 matrix-core path.
+    elapsed_bf16x3 = forced_mode_steps(ops.NET_BF16X3)
+    elapsed_f32 = forced_mode_steps(ops.NET_F32)
+
+    # Sustained: >= --sustained-seconds of back-to-back steps in the default mode (clocks and thermals over seconds
+    # instead of the 25 ms of the timed region; also something a once-per-second busy sampler can see)
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = max(args.steps, int(np.ceil(args.sustained_seconds / (elapsed / args.steps))))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            hot_path_step(False)
+        ve._flush_stats()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        sustained = {"steps": n_sus, "seconds": dt, "value": n_sus * T * N * world / dt, "ms_per_step": 1e3 * dt / n_sus}
+
+    # Where a step's time goes: 16 more back-to-back steps whose kernel dispatches all carry start/stop timestamps
+    # (ppo_prof_arm: hipExtLaunchKernelGGL's events time the dispatch packet itself, like rocprofv3 --kernel-trace;
+    # a torch.cuda.Event pair around a launch also times two barrier packets and reads 25-50 us high).  Outside the
+    # timed region: an event pair costs ~5.7 us of the step it sits in.  A step launches, in this order: the
+    # episode statistics of the PREVIOUS rollout (3 kernels), the rollout kernel, GAE.
+    us = C.c_float()
+
+    def slot_us(slot):
+        _lib.check(lib.ppo_prof_elapsed_us(slot, C.byref(us)), "ppo_prof_elapsed_us")
+        return us.value
+
+    for _ in range(4):
+        hot_path_step(False)
+    per_kernel = []
+    for k in range(16):
+        _lib.check(lib.ppo_prof_arm(5 * k, 5), "ppo_prof_arm")
+        hot_path_step(False)
+    _lib.check(lib.ppo_prof_arm(0, 0), "ppo_prof_arm")
     torch.cuda.synchronize()
-    ro_ms = float(np.median([a.elapsed_time(b) for a, b in pairs[2:]]))
+    per_kernel = np.array([[slot_us(5 * k + j) for j in range(5)] for k in range(4, 16)])   # (first four: settle)
+    stats_us, ro_us, gae_bd_us = per_kernel[:, :3].sum(1).mean(), per_kernel[:, 3].mean(), per_kernel[:, 4].mean()
+    ro_ms = float(ro_us) * 1e-3
     waves = (N + 63) // 64 if N > 32768 else (N + 31) // 32          # 64- or 32-env waves (csrc/rollout.hip)
     mfma_per_wave_step = 60 if N > 32768 else 30                      # 32x32x16 f16 MFMAs, joint net
     ro_flops = mfma_per_wave_step * 2 * 32 * 32 * 16 * waves * T
     ro_bytes = (4 * probe.observation_space.shape[0] + 24) * N * T    # states + action, log-prob, value, reward, 2 flags
 
-    us = C.c_float()
-    gae_us = []
-    for slot in gae_events:
-        _lib.check(lib.ppo_prof_elapsed_us(slot, C.byref(us)), "ppo_prof_elapsed_us")
-        gae_us.append(us.value)
+    gae_us = [slot_us(slot) for slot in gae_events]
     gae_ms = float(np.mean(gae_us)) * 1e-3 if gae_us else float("nan")
     n_trunc = float((ve.trunc_flags != 0).sum())   # truncated cells of the last rollout (4 B of end value each)
     gae_bytes = int(GAE_BYTES_PER_ELEM * T * N + 4 * n_trunc)
@@ -328,6 +374,7 @@ def main():
         if rec.get("T") == T and rec.get("N") == N:
             traffic = rec.get("hbm_bytes_per_launch")
 
+    line = None
     if rank == 0:
         total_steps = args.steps * T * N * world
         line = {
@@ -337,13 +384,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64 env physics; f32 network, buffers, GAE (network products in the library's auto mode: two-piece "
                      "f16 splits of both operands, 22 bits each, f32 accumulate, chosen per parameter set only where that "
-                     "measures as accurate as PyTorch's f32 forward -- tests/test_gpu_net_precision.py; exact f32 otherwise)",
+                     "measures as accurate as PyTorch's f32 forward -- tests/test_gpu_net_precision.py; three-piece bf16 "
+                     "splits, f32-grade at every weight scale, otherwise: value_f32_grade is the whole run in that mode)",
             "data": "synthetic",
+            "ranks_seen": ranks_seen, "rank_devices": devices, "backend": backend if world > 1 else None,
             "clock_settle_steps": args.settle_steps,
             "value_from_idle_clocks": total_steps / elapsed_idle,
             "ms_per_step_from_idle_clocks": 1e3 * elapsed_idle / args.steps,
+            "value_f32_grade": total_steps / elapsed_bf16x3,
+            "ms_per_step_f32_grade": 1e3 * elapsed_bf16x3 / args.steps,
             "value_with_exact_f32_products": total_steps / elapsed_f32,
             "ms_per_step_with_exact_f32_products": 1e3 * elapsed_f32 / args.steps,
+            "sustained": sustained,
             "config": {"workload": f"{kind} batched stepping + GAE, N={N} envs/GPU x T={T}, dense 64-64 tanh policy "
                                    f"(joint net, f32) inside the whole-rollout kernel, BASELINE configs[1]",
                        "num_envs_per_gpu": N, "rollout_len": T, "net_mode": f"auto -> {mode_used}", "parallelism": f"env-sharded x{world}, no data-path collective"},
@@ -357,9 +409,14 @@ def main():
                                  "before, is served by the 256 MiB Infinity Cache; with cold inputs (tools/tune_gae.py, "
                                  "4 rotating buffer sets) the same kernel takes 35.8 us = 58.7 % of peak, and `traffic` "
                                  "is the L2-to-fabric byte count of that cold run"},
+            "step_breakdown_us": {"episode_statistics_3_kernels": float(stats_us), "k_rollout": float(ro_us),
+                                  "k_gae": float(gae_bd_us), "sum": float(stats_us + ro_us + gae_bd_us),
+                                  "note": "kernel durations from dispatch timestamps (ppo_prof_arm), means over 12 "
+                                          "back-to-back steps after the timed region; ms_per_step minus the sum is "
+                                          "dispatch gaps between the five launches of a step"},
         }
         line["rollout_kernel"] = {
-            "kernel": "k_rollout (ppo_rollout_fused), PPO_NET_F16_SPLIT", "bound": "valu-issue",
+            "kernel": f"k_rollout (ppo_rollout_fused), {mode_used}", "bound": "valu-issue",
             "avg_launch_us": ro_ms * 1e3,
             "mfma_f16_tflops": ro_flops / (ro_ms * 1e-3) / 1e12, "mfma_f16_peak_tflops": MFMA_F16_PEAK_TFLOPS,
             "mfma_frac": ro_flops / (ro_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
@@ -371,8 +428,8 @@ def main():
                                 if (kind == "cartpole" and N > 32768) else None),
             "note": "neither an HBM- nor an MFMA-bound kernel: by PMC (profiles/r02_rollout_pmc_f16_split.txt) "
                     "the VALU is active 71 % of the wave cycles (1035 instructions per wave and step: tanh, operand "
-                    "splits, heads, f64 physics, Philox), the 60 f16 MFMAs per wave and step are busy 25 %; event pair "
-                    "around the launch in a back-to-back loop after the timed region, median of 6"}
+                    "splits, heads, f64 physics, Philox), the 60 f16 MFMAs per wave and step are busy 25 %; duration "
+                    "from the dispatch's own start/stop timestamps (step_breakdown_us)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, args.cpu_sample_envs, T, args.seed)
             line["cpu_baseline"].update(cpu_gae_loss_baseline(T, N, args.seed))
@@ -380,17 +437,21 @@ def main():
     ve.close()
     del ve
     torch.cuda.empty_cache()
+    status = 0
     if not args.no_train_step:
         # The headline line must not be lost to this extra section: an exception is reported inside the
         # line, and if the section does not finish in time (a rank stuck in a collective because another
-        # one failed), a watchdog prints the line without it and ends the process.
+        # one failed), a watchdog prints the line without it and ends the process -- with a NON-ZERO status on
+        # every rank, so that the run is recorded as failed and a launcher ends the other ranks.
         import threading
 
         def give_up():
+            msg = f"bench.py rank {rank}: train_step section did not finish within {args.train_step_timeout} s; giving up"
             if rank == 0:
                 line["train_step"] = {"error": f"did not finish within {args.train_step_timeout} s"}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            print(msg, file=sys.stderr, flush=True)
+            os._exit(3)
 
         watchdog = threading.Timer(args.train_step_timeout, give_up)
         watchdog.daemon = True
@@ -399,15 +460,40 @@ def main():
             rates = train_step_rates(kind, N, T, world, args.seed)
         except Exception as e:
             rates = {"error": f"{type(e).__name__}: {e}"}
-        if world > 1:
-            torch.distributed.barrier()              # every rank is through before the watchdog is disarmed
+            print(f"bench.py rank {rank}: train_step section failed: {rates['error']}", file=sys.stderr, flush=True)
+            status = 4
+        D.barrier("bench_train_step_done")           # every rank is through before the watchdog is disarmed
         watchdog.cancel()
         if rank == 0:
             line["train_step"] = rates
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        D.barrier("bench_exit")
+        torch.distributed.destroy_process_group()
+    if status:
+        sys.exit(status)
+
+
+def dry_run(args, D, world, rank):
+    """--dry: everything around the GPU work -- self-launch / torchrun environment, rendezvous, a collective that
+    counts the ranks -- and nothing on the GPU.  Runs on a CPU box (gloo); tests/test_bench_launch.py uses it."""
+    use_cuda = os.environ.get("PPO_AMD_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.is_available() \
+        and torch.cuda.device_count() >= world
+    backend = "nccl" if use_cuda else "gloo"
+    if world > 1:
+        D.init_from_env(backend)
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    ranks_seen = int(D.sum_tensor(torch.ones(1, device=dev), "ranks_seen").item())
+    devices = D.gather_rows(torch.tensor([float(dev.index if use_cuda else -1)], device=dev), "rank_devices")
+    slowest = D.max_scalar(float(rank), "bench_time_max")
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/sec (rollout+GAE)", "value": None, "unit": "env-steps/s", "n_gpus": world,
+                          "ranks_seen": ranks_seen, "rank_devices": devices.reshape(-1).int().tolist(), "backend": backend,
+                          "max_rank_seen_by_max_reduce": slowest, "dry": True, "steps": 0, "warmup": 0,
+                          "self_launched": bool(os.environ.get("PPO_AMD_SELF_LAUNCHED"))}), flush=True)
+    if world > 1:
+        D.barrier("bench_exit")
         torch.distributed.destroy_process_group()
 
 

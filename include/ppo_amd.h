@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define PPO_AMD_ABI_VERSION 1
+/* 2: the sampling stream of ppo_categorical_sample / ppo_rollout_fused draws one Philox block per FOUR policy
+ *    steps (counter = step / 4, word = step % 4; version 1 drew one block per step), so a run resumed across the
+ *    two versions samples different actions; PPO_NET_BF16X3 added; private hooks changed. */
+#define PPO_AMD_ABI_VERSION 2
 
 #define PPO_ENV_CARTPOLE 0 /* CartPole-v1: obs_dim 4, actions {0,1}   */
 #define PPO_ENV_ACROBOT 1  /* Acrobot-v1:  obs_dim 6, actions {0,1,2} */
@@ -46,6 +49,11 @@ extern "C" {
                                 (22 significant bits per operand, f32 accumulate): ~1.9x faster.
                                 As accurate as f32 unless the backbone weights are tiny: see
                                 split_diag of ppo_rollout_pack_params */
+#define PPO_NET_BF16X3 2     /* v_mfma_f32_32x32x16_bf16 on three-piece bf16 splits of both operands: every f32
+                                operand is represented exactly, a product is its six largest cross terms in one
+                                f32 accumulator.  As accurate as PPO_NET_F32 at every weight scale (measured),
+                                ~1.7x faster than it: the f32-grade mode, and what to use outside the limits of
+                                PPO_NET_F16_SPLIT */
 
 int ppo_abi_version(void);
 
@@ -287,7 +295,7 @@ size_t ppo_rollout_param_floats(int kind, int joint, int net_mode);
  * straight from the nn.Linear tensors (weights row-major [out, in], f32), so that the rollout that
  * follows an optimiser step never waits for host work.
  *   kind       fixes obs (4 / 6) and A (2 / 3);  joint != 0: va_* are ignored (may be NULL)
- *   net_mode   PPO_NET_F32 or PPO_NET_F16_SPLIT (the layout differs)
+ *   net_mode   PPO_NET_F32, PPO_NET_F16_SPLIT or PPO_NET_BF16X3 (the layouts differ)
  *   params_out ppo_rollout_param_floats(kind, joint, net_mode) floats
  *   split_diag device f32[3] or NULL: what decides whether PPO_NET_F16_SPLIT is as accurate as f32
  *              for this parameter set (w' = 2 log2(e) w is the value the split kernels split):
@@ -324,7 +332,7 @@ int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w
  *   reward_sum  device f64 or NULL: the sum of all T*N rewards is ADDED to it (the caller zeroes
  *   it) -- SyncVecEnv.total_return (src/ppo.py:318, :348); per-env f32 sums over time, f64 across envs
  * Env state arguments and rings as in ppo_env_step; row T-1 gets the forced truncation.
- * net_mode: PPO_NET_F32 or PPO_NET_F16_SPLIT; `params` must have been packed for that mode.
+ * net_mode: PPO_NET_F32, PPO_NET_F16_SPLIT or PPO_NET_BF16X3; `params` must have been packed for that mode.
  * Values / log-probs agree with the PyTorch f32 forward of the same parameters to ~1e-6 (different
  * summation order than hipBLASLt; the split mode keeps 22 bits per operand), not bit for bit.
  */

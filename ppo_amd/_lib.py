@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libppo_amd.so")
 
+ABI_VERSION = 2   # include/ppo_amd.h: PPO_AMD_ABI_VERSION
+
 _vp, _i, _l, _d, _u64, _sz = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_uint64, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/ppo_amd.h one to one
@@ -55,6 +57,7 @@ _PRIVATE = {
     "ppo_rollout_fused_ex": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_gae_dense_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
+    "ppo_prof_arm": (_i, [_i, _i]),
     "ppo_prof_elapsed_us": (_i, [_i, C.POINTER(C.c_float)]),
 }
 
@@ -78,8 +81,9 @@ def load():
     for name, (res, args) in {**SIGNATURES, **_PRIVATE}.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
-    if lib.ppo_abi_version() != 1:
-        raise PpoAmdError("libppo_amd.so ABI version mismatch")
+    if lib.ppo_abi_version() != ABI_VERSION:
+        raise PpoAmdError(f"libppo_amd.so has ABI version {lib.ppo_abi_version()}, this binding expects {ABI_VERSION}: rebuild it "
+                          "(make -C ppo_amd/csrc)")
     _lib = lib
     return lib
 

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 PPO kernels (wave64, CDNA4).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/ppo_amd.h"
@@ -15,6 +16,36 @@
 static inline int ppo_launch_status() { return (int)hipGetLastError(); }
 
 static inline bool ppo_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// ---------------------------------------------------------------------------
+// Bench-only kernel timing (private symbols ppo_prof_arm / ppo_prof_elapsed_us / ppo_gae_dense_timed; not part
+// of include/ppo_amd.h).  ppo_prof_arm(first, count) makes the next `count` kernel launches that go through
+// PPO_LAUNCH carry a start/stop event pair (hipExtLaunchKernelGGL timestamps the dispatch packet itself; a
+// plain hipEventRecord pair around a launch also times two barrier packets, +25..50 us on this stack;
+// rocprofv3 --kernel-trace agrees with this form).  The slots are the library's only process-wide
+// state: one bench thread, not thread-safe.  Un-armed (always, outside bench.py) the macro is a plain launch.
+constexpr int PPO_PROF_SLOTS = 256;
+struct PpoProf {
+    hipEvent_t start[PPO_PROF_SLOTS], stop[PPO_PROF_SLOTS];
+    bool have[PPO_PROF_SLOTS];
+    int next, left;                // slot of the next armed launch; armed launches still to come
+};
+extern PpoProf g_ppo_prof;         // gae.hip
+static inline int ppo_prof_take()
+{
+    if (g_ppo_prof.left <= 0) return -1;
+    g_ppo_prof.left -= 1;
+    return g_ppo_prof.next++;
+}
+#define PPO_LAUNCH(kern, grid, block, stream, ...)                                                              \
+    do {                                                                                                        \
+        const int ps_ = ppo_prof_take();                                                                        \
+        if (ps_ >= 0)                                                                                           \
+            hipExtLaunchKernelGGL(kern, grid, block, 0, stream, g_ppo_prof.start[ps_], g_ppo_prof.stop[ps_], 0, \
+                                  __VA_ARGS__);                                                                 \
+        else                                                                                                    \
+            hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                                      \
+    } while (0)
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (counter-based; integer arithmetic only, so host oracle and device

@@ -16,19 +16,10 @@
 // (the library is built with -ffp-contract=off), so results are bit-identical to
 // torch-CPU for flags in {0,1} and reproduce its (1 - terminations) arithmetic otherwise.
 #include "common.h"
-#include <hip/hip_ext.h>
+
+PpoProf g_ppo_prof;   // bench-only launch timing, see common.h
 
 namespace {
-
-// Bench-only kernel timing (private symbols ppo_gae_dense_timed / ppo_prof_elapsed_us; not part of
-// include/ppo_amd.h): a timed launch goes through hipExtLaunchKernelGGL with a start/stop event pair,
-// which timestamps the dispatch packet itself.  A plain hipEventRecord pair around the launch
-// also times two barrier packets (+25..50 us on this stack); rocprofv3 agrees with this form.
-// The event slots are the library's only process-wide state: one bench thread, not thread-safe.
-constexpr int PROF_SLOTS = 256;
-hipEvent_t g_prof_start[PROF_SLOTS], g_prof_stop[PROF_SLOTS];
-bool g_prof_have[PROF_SLOTS];
-
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using F = float; using I = int; };
@@ -346,18 +337,13 @@ template <int VEC, int U, int BLOCK> int launch_gae_sparse_block(const GaeArgs &
     return ppo_launch_status();
 }
 
-template <int VEC, int U, bool NT = false> int launch_gae_sparse(const GaeArgs &a, hipStream_t s, int slot = -1)
+template <int VEC, int U, bool NT = false> int launch_gae_sparse(const GaeArgs &a, hipStream_t s)
 {
     const long threads = a.N / VEC;
     const long waves = (threads + 63) / 64;
     const int block = waves <= 2048 ? 64 : 256;
     const long grid = (threads + block - 1) / block;
-    if (slot >= 0) {
-        hipExtLaunchKernelGGL((k_gae_sparse<VEC, U, NT>), dim3((unsigned)grid), dim3(block), 0, s, g_prof_start[slot],
-                              g_prof_stop[slot], 0, a);
-        return ppo_launch_status();
-    }
-    hipLaunchKernelGGL((k_gae_sparse<VEC, U, NT>), dim3((unsigned)grid), dim3(block), 0, s, a);
+    PPO_LAUNCH((k_gae_sparse<VEC, U, NT>), dim3((unsigned)grid), dim3(block), s, a);
     return ppo_launch_status();
 }
 
@@ -451,7 +437,7 @@ template <int VEC, int U, bool DENSE_EV> int launch_gae(const GaeArgs &a, hipStr
     const long waves = (threads + 63) / 64;
     const int block = waves <= 2048 ? 64 : 256;  // few columns: spread the waves over all CUs
     const long grid = (threads + block - 1) / block;
-    hipLaunchKernelGGL((k_gae<VEC, U, DENSE_EV>), dim3((unsigned)grid), dim3(block), 0, s, a);
+    PPO_LAUNCH((k_gae<VEC, U, DENSE_EV>), dim3((unsigned)grid), dim3(block), s, a);
     return ppo_launch_status();
 }
 
@@ -459,16 +445,15 @@ template <int VEC, int U, bool DENSE_EV> int launch_gae(const GaeArgs &a, hipStr
 // buffer, 2-7 fetch it only where a truncation is flagged; 6-7 use non-temporal accesses (measured
 // inside bench.py: <2,8> 34.0 us, <2,8,nt> 39.5, <1,8> 35.2, <1,8,nt> 33.5 -- no clear win, and the
 // <2,8> form is sensitive to how the compiler schedules its loads, so its source is left as it is).
-int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s, int slot = -1)
+int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s)
 {
-    if (slot >= 0 && variant != 3 && variant != 5) return (int)hipErrorInvalidValue;   // timed: the shipped forms only
     switch (variant) {
     case 0: return launch_gae<1, 8, true>(a, s);
     case 1: return launch_gae<2, 4, true>(a, s);
     case 2: return launch_gae_sparse<1, 4>(a, s);
-    case 3: return launch_gae_sparse<1, 8>(a, s, slot);
+    case 3: return launch_gae_sparse<1, 8>(a, s);
     case 4: return launch_gae_sparse<2, 4>(a, s);
-    case 5: return launch_gae_sparse<2, 8>(a, s, slot);
+    case 5: return launch_gae_sparse<2, 8>(a, s);
     case 6: return launch_gae_sparse<2, 8, true>(a, s);
     case 7: return launch_gae_sparse<1, 8, true>(a, s);
     case 8: return launch_gae_sparse4<2, 8>(a, s);
@@ -524,7 +509,7 @@ extern "C" {
 
 static int gae_dense_launch(const float *rewards, const float *values, const float *end_value_dense,
                             const int *done, const int *trunc, double gamma, double lam, float *adv,
-                            float *ret, int T, int N, int variant, int slot, void *stream)
+                            float *ret, int T, int N, int variant, void *stream)
 {
     PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
     PPO_REQUIRE(T >= 0 && N >= 0);
@@ -537,7 +522,7 @@ static int gae_dense_launch(const float *rewards, const float *values, const flo
                 (!ret || ppo_aligned(ret, al)));
     GaeArgs a{rewards, values, end_value_dense, done, trunc, adv, ret, nullptr, 0, nullptr,
               (float)gamma, (float)(gamma * lam), T, N};
-    return launch_gae_dense_variant(a, variant, (hipStream_t)stream, slot);
+    return launch_gae_dense_variant(a, variant, (hipStream_t)stream);
 }
 
 // Measured on MI355X at T=128, N=65536: sparse end values, two columns per lane,
@@ -556,8 +541,7 @@ int ppo_gae_dense_variant(const float *rewards, const float *values, const float
                           const int *done, const int *trunc, double gamma, double lam, float *adv,
                           float *ret, int T, int N, int variant, void *stream)
 {
-    return gae_dense_launch(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N, variant, -1,
-                            stream);
+    return gae_dense_launch(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N, variant, stream);
 }
 
 int ppo_gae_dense(const float *rewards, const float *values, const float *end_value_dense,
@@ -566,34 +550,48 @@ int ppo_gae_dense(const float *rewards, const float *values, const float *end_va
 {
     PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
     return gae_dense_launch(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
-                            gae_default_variant(rewards, values, end_value_dense, done, trunc, adv, ret, N), -1, stream);
+                            gae_default_variant(rewards, values, end_value_dense, done, trunc, adv, ret, N), stream);
 }
 
-// Bench-only (private): ppo_gae_dense whose dispatch is timed into event slot `slot`; read the slot
-// back with ppo_prof_elapsed_us (which waits for it).  Single bench thread; slots are process-wide.
+// Bench-only (private): the next `count` kernel launches of this library are timed into event slots
+// first_slot .. first_slot + count - 1 (PPO_LAUNCH in common.h); read a slot back with ppo_prof_elapsed_us
+// (which waits for it).  Single bench thread; slots are process-wide.
+int ppo_prof_arm(int first_slot, int count)
+{
+    PPO_REQUIRE(first_slot >= 0 && count >= 0 && first_slot + count <= PPO_PROF_SLOTS);
+    for (int k = first_slot; k < first_slot + count; ++k) {
+        if (g_ppo_prof.have[k]) continue;
+        hipError_t e = hipEventCreate(&g_ppo_prof.start[k]);
+        if (e == hipSuccess) e = hipEventCreate(&g_ppo_prof.stop[k]);
+        if (e != hipSuccess) return (int)e;
+        g_ppo_prof.have[k] = true;
+    }
+    g_ppo_prof.next = first_slot;
+    g_ppo_prof.left = count;
+    return 0;
+}
+
+// ppo_gae_dense whose dispatch is timed into event slot `slot`
 int ppo_gae_dense_timed(const float *rewards, const float *values, const float *end_value_dense,
                         const int *done, const int *trunc, double gamma, double lam, float *adv,
                         float *ret, int T, int N, int slot, void *stream)
 {
     PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
-    PPO_REQUIRE(slot >= 0 && slot < PROF_SLOTS && T > 0 && N > 0);
-    if (!g_prof_have[slot]) {
-        hipError_t e = hipEventCreate(&g_prof_start[slot]);
-        if (e == hipSuccess) e = hipEventCreate(&g_prof_stop[slot]);
-        if (e != hipSuccess) return (int)e;
-        g_prof_have[slot] = true;
-    }
-    return gae_dense_launch(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
-                            gae_default_variant(rewards, values, end_value_dense, done, trunc, adv, ret, N), slot, stream);
+    PPO_REQUIRE(slot >= 0 && slot < PPO_PROF_SLOTS && T > 0 && N > 0);
+    const int rc = ppo_prof_arm(slot, 1);
+    if (rc) return rc;
+    const int out = ppo_gae_dense(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N, stream);
+    g_ppo_prof.left = 0;                           // (an argument check may have returned before the launch)
+    return out;
 }
 
 int ppo_prof_elapsed_us(int slot, float *us)
 {
-    PPO_REQUIRE(slot >= 0 && slot < PROF_SLOTS && g_prof_have[slot] && us);
-    hipError_t e = hipEventSynchronize(g_prof_stop[slot]);
+    PPO_REQUIRE(slot >= 0 && slot < PPO_PROF_SLOTS && g_ppo_prof.have[slot] && us);
+    hipError_t e = hipEventSynchronize(g_ppo_prof.stop[slot]);
     if (e != hipSuccess) return (int)e;
     float ms = 0.0f;
-    e = hipEventElapsedTime(&ms, g_prof_start[slot], g_prof_stop[slot]);
+    e = hipEventElapsedTime(&ms, g_ppo_prof.start[slot], g_ppo_prof.stop[slot]);
     *us = ms * 1000.0f;
     return (int)e;
 }

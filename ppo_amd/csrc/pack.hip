@@ -54,6 +54,24 @@ __device__ __forceinline__ uint32_t split_piece(double v, int piece)
     return f16_bits(v - (double)(float)hi);
 }
 
+// x (already scaled, float64) -> bits of its bf16 piece 0, 1 or 2: b0 = bf16(x), b1 = bf16(x - b0),
+// b2 = bf16(x - b0 - b1), each rounded to nearest even (double -> float -> bf16); the residuals are exact in
+// float64.  b0 + b1 + b2 carries 24+ significant bits of x: the f32 value of the scaled weight, or better.
+__device__ __forceinline__ double bf16_round(double x, uint32_t &bits)
+{
+    uint32_t u = __float_as_uint((float)x);
+    u += 0x7fffu + ((u >> 16) & 1u);                   // round to nearest even on the upper 16 bits (finite inputs)
+    bits = u >> 16;
+    return (double)__uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t split3_piece(double v, int piece)
+{
+    uint32_t bits;
+    for (int q = 0; q < piece; ++q) v -= bf16_round(v, bits);
+    bf16_round(v, bits);
+    return bits;
+}
+
 // One 32-bit word of a backbone in the PPO_NET_F32 layout: F1[S1][2][64], F2[33][2][64]
 __device__ float f32_backbone_word(const Backbone &b, int obs, int k)
 {
@@ -70,35 +88,38 @@ __device__ float f32_backbone_word(const Backbone &b, int obs, int k)
     return col < K ? w[row * K + col] : 0.0f;
 }
 
-// One 32-bit word (two f16) of a backbone in the PPO_NET_F16_SPLIT layout
-__device__ uint32_t f16_backbone_word(const Backbone &b, int obs, int k)
+// One 32-bit word (two 16-bit pieces) of a backbone in the PPO_NET_F16_SPLIT (P = 2, f16 pieces) or
+// PPO_NET_BF16X3 (P = 3, bf16 pieces) layout
+template <int P> __device__ uint32_t split_backbone_word(const Backbone &b, int obs, int k)
 {
-    if (k >= BB16_W1 + BB16_W2) {                      // B2[op][r][lane] f32
-        k -= BB16_W1 + BB16_W2;
+    constexpr int W1 = bb16_w1(P), W2 = bb16_w2(P);
+    if (k >= W1 + W2) {                                // B2[op][r][lane] f32
+        k -= W1 + W2;
         const int op = k >> 10, r = (k >> 6) & 15, l = k & 63;
         return __float_as_uint((float)((double)b.b2[unit(op, r, l >> 5)] * TANH_SCALE));
     }
+    const auto piece_bits = [](double v, int piece) { return P == 2 ? split_piece(v, piece) : split3_piece(v, piece); };
     uint32_t word = 0;
-    if (k < BB16_W1) {                                 // W1[op][piece][lane][4]
-        const int wd = k & 3, l = (k >> 2) & 63, piece = (k >> 8) & 1, op = k >> 9, row = 32 * op + (l & 31);
+    if (k < W1) {                                      // W1[op][piece][lane][4]
+        const int wd = k & 3, l = (k >> 2) & 63, piece = (k >> 8) % P, op = (k >> 8) / P, row = 32 * op + (l & 31);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int i = 2 * wd + e;
             double v = 0.0;
             if (i < obs) v = (double)b.w1[row * obs + i] * TANH_SCALE;
             else if (i == obs) v = (double)b.b1[row] * TANH_SCALE;
-            word |= split_piece(v, piece) << (16 * e);
+            word |= piece_bits(v, piece) << (16 * e);
         }
         return word;
     }
-    k -= BB16_W1;                                      // W2[j][op][piece][lane][4]
-    const int wd = k & 3, l = (k >> 2) & 63, piece = (k >> 8) & 1, op = (k >> 9) & 1, j = k >> 10;
+    k -= W1;                                           // W2[j][op][piece][lane][4]
+    const int wd = k & 3, l = (k >> 2) & 63, piece = (k >> 8) % P, op = ((k >> 8) / P) & 1, j = (k >> 8) / (2 * P);
     const int row = 32 * op + (l & 31);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int i = 2 * wd + e;
         const int col = unit(j >> 1, 8 * (j & 1) + i, l >> 5);
-        word |= split_piece((double)b.w2[row * H + col] * TANH_SCALE, piece) << (16 * e);
+        word |= piece_bits((double)b.w2[row * H + col] * TANH_SCALE, piece) << (16 * e);
     }
     return word;
 }
@@ -168,7 +189,8 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_pack_params(PackArgs a)
     if (k < nbb * a.bb_words) {
         const Backbone &b = k < a.bb_words ? a.pi : a.va;
         const int kk = k < a.bb_words ? k : k - a.bb_words;
-        word = a.net_mode == PPO_NET_F32 ? __float_as_uint(f32_backbone_word(b, a.obs, kk)) : f16_backbone_word(b, a.obs, kk);
+        word = a.net_mode == PPO_NET_F32 ? __float_as_uint(f32_backbone_word(b, a.obs, kk))
+               : a.net_mode == PPO_NET_BF16X3 ? split_backbone_word<3>(b, a.obs, kk) : split_backbone_word<2>(b, a.obs, kk);
     } else {
         word = __float_as_uint(head_word(a, k - nbb * a.bb_words));
     }
@@ -187,7 +209,7 @@ int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w
 {
     const int obs = ppo_env_obs_dim(kind);
     PPO_REQUIRE(obs > 0 && obs < 8 && obs % 2 == 0);
-    PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT);
+    PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT || net_mode == PPO_NET_BF16X3);
     PPO_REQUIRE(pi_w1 && pi_b1 && pi_w2 && pi_b2 && policy_w && policy_b && critic_w && critic_b && params_out);
     PPO_REQUIRE(joint || (va_w1 && va_b1 && va_w2 && va_b2));
     PackArgs a{};
@@ -196,7 +218,7 @@ int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w
     a.policy_w = policy_w; a.policy_b = policy_b; a.critic_w = critic_w; a.critic_b = critic_b;
     a.out = params_out; a.split_diag = split_diag;
     a.obs = obs; a.A = kind == PPO_ENV_CARTPOLE ? 2 : 3; a.joint = joint ? 1 : 0; a.net_mode = net_mode;
-    a.bb_words = net_mode == PPO_NET_F32 ? backbone_floats(obs) : BB16_WORDS;
+    a.bb_words = net_mode == PPO_NET_F32 ? backbone_floats(obs) : bb16_words(net_mode == PPO_NET_BF16X3 ? 3 : 2);
     a.total_words = a.bb_words * (joint ? 1 : 2) + HEAD_FLOATS;
     const unsigned grid = (unsigned)((a.total_words + PACK_BLOCK - 1) / PACK_BLOCK) + 1u;   // + the margin block
     hipLaunchKernelGGL(k_pack_params, dim3(grid), dim3(PACK_BLOCK), 0, (hipStream_t)stream, a);

@@ -298,8 +298,33 @@ __device__ __forceinline__ f32x2 tanh2v_prescaled(float x0, float x1)
     return __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
 }
 
-struct RegW16 {
-    Frag16 w1[2][2], w2[4][2][2];
+// ---- network mode 2: bf16 MFMA on three-piece splits (every f32 operand represented exactly) ----
+// x = x0 + x1 + x2 with bf16 pieces (8 significand bits each, f32's exponent range; mfma_split.h), so nothing
+// is lost in the operands -- weights or activations, large or tiny.  A product x w is the six cross terms of
+// order <= 2 (x0 w0; x0 w1, x1 w0; x0 w2, x1 w1, x2 w0) as v_mfma_f32_32x32x16_bf16 into ONE f32 accumulator,
+// small terms first; the three dropped terms (x1 w2, x2 w1, x2 w2) are below 2^-23 |x w| in the worst case
+// and ~2^-25 on average, the size of ONE f32 rounding -- and the matrix core adds its sixteen exact products
+// of a k-step with fewer roundings than a sixteen-step fmaf chain.  Measured (tests/test_gpu_net_precision.py,
+// profiles/r03_net_precision.txt): as accurate as the exact-f32 kernels at every weight scale.  192 MFMA
+// cycles per 16 k against 512 for v_mfma_f32_32x32x2_f32, and bf16 MFMAs co-execute with the wave's VALU work.
+// Layouts as in mode 1 with three pieces instead of two (W1[op][piece 3][lane][4], W2[j][op][piece 3][lane][4]).
+struct SchemeF16 {          // mode 1: two f16 pieces, three terms
+    static constexpr int P = 2, NT = 3;
+    __device__ static constexpr int tw(int t) { return t == 0 ? 1 : 0; }      // weight piece of term t
+    __device__ static constexpr int ta(int t) { return t == 1 ? 1 : 0; }      // activation piece of term t
+    __device__ static __forceinline__ f32x16 mfma(const Frag16 &a, const Frag16 &b, f32x16 c) { return mfma16(a, b, c); }
+    __device__ static __forceinline__ void split(float a0, float a1, uint32_t (&p)[2]) { split2(a0, a1, p[0], p[1]); }
+};
+struct SchemeBF16 {         // mode 2: three bf16 pieces, six terms, ascending magnitude
+    static constexpr int P = 3, NT = 6;
+    __device__ static constexpr int tw(int t) { return t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0; }   // w2 a0, w1 a1, w0 a2, w1 a0, w0 a1, w0 a0
+    __device__ static constexpr int ta(int t) { return t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0; }
+    __device__ static __forceinline__ f32x16 mfma(const Frag16 &a, const Frag16 &b, f32x16 c) { return mfma16_bf16(a, b, c); }
+    __device__ static __forceinline__ void split(float a0, float a1, uint32_t (&p)[3]) { split3_bf16(a0, a1, p[0], p[1], p[2]); }
+};
+
+template <int P> struct RegW16 {
+    Frag16 w1[2][P], w2[4][2][P];
     f32x16 b2[2];
     __device__ __forceinline__ f32x16 bias2(int op) const { return b2[op]; }
     __device__ __forceinline__ void load(const float *__restrict__ g, int lane)
@@ -308,8 +333,8 @@ struct RegW16 {
 #pragma unroll
         for (int op = 0; op < 2; ++op)
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const uint4 x = v[(op * 2 + pc) * 64 + lane];
+            for (int pc = 0; pc < P; ++pc) {
+                const uint4 x = v[(op * P + pc) * 64 + lane];
                 w1[op][pc] = Frag16{{x.x, x.y, x.z, x.w}};
             }
 #pragma unroll
@@ -317,19 +342,19 @@ struct RegW16 {
 #pragma unroll
             for (int op = 0; op < 2; ++op)
 #pragma unroll
-                for (int pc = 0; pc < 2; ++pc) {
-                    const uint4 x = v[BB16_W1 / 4 + ((j * 2 + op) * 2 + pc) * 64 + lane];
+                for (int pc = 0; pc < P; ++pc) {
+                    const uint4 x = v[bb16_w1(P) / 4 + ((j * 2 + op) * P + pc) * 64 + lane];
                     w2[j][op][pc] = Frag16{{x.x, x.y, x.z, x.w}};
                 }
 #pragma unroll
         for (int op = 0; op < 2; ++op)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) b2[op][r] = g[BB16_W1 + BB16_W2 + (op * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; ++r) b2[op][r] = g[bb16_w1(P) + bb16_w2(P) + (op * 16 + r) * 64 + lane];
     }
     __device__ __forceinline__ Frag16 get1(int op, int pc) const { return w1[op][pc]; }
     __device__ __forceinline__ Frag16 get2(int j, int op, int pc) const { return w2[j][op][pc]; }
 };
-struct LdsW16 {
+template <int P> struct LdsW16 {
     const float *p;   // LDS copy of one backbone
     int lane;
     __device__ __forceinline__ Frag16 rd(int idx) const
@@ -337,13 +362,13 @@ struct LdsW16 {
         const uint4 x = reinterpret_cast<const uint4 *>(p)[idx * 64 + lane];
         return Frag16{{x.x, x.y, x.z, x.w}};
     }
-    __device__ __forceinline__ Frag16 get1(int op, int pc) const { return rd(op * 2 + pc); }
-    __device__ __forceinline__ Frag16 get2(int j, int op, int pc) const { return rd(BB16_W1 / 256 + (j * 2 + op) * 2 + pc); }
+    __device__ __forceinline__ Frag16 get1(int op, int pc) const { return rd(op * P + pc); }
+    __device__ __forceinline__ Frag16 get2(int j, int op, int pc) const { return rd(bb16_w1(P) / 256 + (j * 2 + op) * P + pc); }
     __device__ __forceinline__ f32x16 bias2(int op) const
     {
         f32x16 b;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) b[r] = p[BB16_W1 + BB16_W2 + (op * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) b[r] = p[bb16_w1(P) + bb16_w2(P) + (op * 16 + r) * 64 + lane];
         return b;
     }
 };
@@ -364,38 +389,45 @@ struct LdsHL {
 // meaningless): half the network work per wave, for batches too small to give every SIMD a wave of 64.
 // NP: policy rows in the head table.  A two-action policy keeps ONE row, the difference of its two
 // logit rows (NetF16::load): softmax and sampling only depend on l1 - l0.
-template <int OBS, int NP, bool DO_P, bool DO_V, int ETILES, class W, class HLT>
+template <class S, int OBS, int NP, bool DO_P, bool DO_V, int ETILES, class W, class HLT>
 __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w, const HLT &hl, int half,
                                               float (&out)[4])
 {
-    constexpr int A = NP;
+    constexpr int A = NP, P = S::P;
     static_assert(OBS < 8, "layer-1 inputs and the bias slot must fit one 8-wide k half");
     // ---- input pieces: (obs, 1.0 for the bias, zeros); env tile e reads them from lane half e
     float in[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) in[k] = k < OBS ? obs[k] : (k == OBS ? 1.0f : 0.0f);
-    Frag16 ih, il;
+    Frag16 ip[P];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split2(in[2 * i], in[2 * i + 1], ih.w[i], il.w[i]);
-    Frag16 b2h[ETILES][4], b2l[ETILES][4];     // layer-2 B operands: tanh(h1) pieces, [env tile][k-step]
+    for (int i = 0; i < 4; ++i) {
+        uint32_t pc[P];
+        S::split(in[2 * i], in[2 * i + 1], pc);
+#pragma unroll
+        for (int q = 0; q < P; ++q) ip[q].w[i] = pc[q];
+    }
+    Frag16 b2[P][ETILES][4];                   // layer-2 B operands: pieces of tanh(h1), [piece][env tile][k-step]
 #pragma unroll
     for (int e = 0; e < ETILES; ++e) {
-        Frag16 bh, bl;
+        Frag16 bp[P];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bh.w[i] = half == e ? ih.w[i] : 0u;
-            bl.w[i] = half == e ? il.w[i] : 0u;
-        }
+        for (int q = 0; q < P; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bp[q].w[i] = half == e ? ip[q].w[i] : 0u;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            f32x16 m = mfma16(w.get1(o, 1), bh, zero16());    // small cross terms first
-            m = mfma16(w.get1(o, 0), bl, m);
-            m = mfma16(w.get1(o, 0), bh, m);
+            f32x16 m = zero16();                               // small cross terms first
+#pragma unroll
+            for (int t = 0; t < S::NT; ++t) m = S::mfma(w.get1(o, S::tw(t)), bp[S::ta(t)], m);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float a0, a1;
                 tanh2_prescaled(m[r], m[r + 1], a0, a1);
-                split2(a0, a1, b2h[e][2 * o + (r >> 3)].w[(r & 7) >> 1], b2l[e][2 * o + (r >> 3)].w[(r & 7) >> 1]);
+                uint32_t pc[P];
+                S::split(a0, a1, pc);
+#pragma unroll
+                for (int q = 0; q < P; ++q) b2[q][e][2 * o + (r >> 3)].w[(r & 7) >> 1] = pc[q];
             }
         }
     }
@@ -415,17 +447,26 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
             if ((j < A && DO_P) || (j == 3 && DO_V)) wn[j] = hl.get4(j, 0, 0);
         // the two output tiles' accumulator chains interleave: each MFMA depends on the one before last
         f32x16 m[2] = {w.bias2(0), w.bias2(1)};
+        if constexpr (P == 2) {                    // (this interleaving of the two small terms is the measured one)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int op = 0; op < 2; ++op) m[op] = mfma16(w.get2(j, op, 1), b2h[e][j], m[op]);
+                for (int op = 0; op < 2; ++op) m[op] = S::mfma(w.get2(j, op, 1), b2[0][e][j], m[op]);
 #pragma unroll
-            for (int op = 0; op < 2; ++op) m[op] = mfma16(w.get2(j, op, 0), b2l[e][j], m[op]);
+                for (int op = 0; op < 2; ++op) m[op] = S::mfma(w.get2(j, op, 0), b2[1][e][j], m[op]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int op = 0; op < 2; ++op) m[op] = S::mfma(w.get2(j, op, 0), b2[0][e][j], m[op]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < S::NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int op = 0; op < 2; ++op) m[op] = S::mfma(w.get2(j, op, S::tw(t)), b2[S::ta(t)][e][j], m[op]);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int op = 0; op < 2; ++op) m[op] = mfma16(w.get2(j, op, 0), b2h[e][j], m[op]);
         // heads: four units at a time; the weights of the next group are requested from LDS before
         // the current group is consumed, so that the read latency hides behind its tanh work
 #pragma unroll
@@ -458,8 +499,9 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
     }
 }
 
-template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
+template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     static constexpr int OBS = OBS_, A = A_, WAVE_ENVS = 32 * ETILES_;
+    static constexpr int BB16_WORDS = bb16_words(S::P), BB16_B2 = ppo_net::BB16_B2;
     static constexpr bool JOINT = JOINT_;
     // Two actions: only l1 - l0 matters to softmax, log-probs and the sampled action, so the head
     // table holds the difference row (and bias) in slot 0 -- one policy dot product instead of two;
@@ -468,8 +510,8 @@ template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     static constexpr int NP = DIFF ? 1 : A_;
     static constexpr int HL_WORDS = 4 * 2 * 16 * 64;
     static constexpr int LDS_WORDS = (JOINT ? 0 : BB16_WORDS) + HL_WORDS + BB16_B2 + 4;
-    RegW16 P;
-    LdsW16 V;
+    RegW16<S::P> P;
+    LdsW16<S::P> V;
     LdsHL hs;
     float bias4[4];
     int half;
@@ -503,8 +545,8 @@ template <int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     template <bool DO_P, bool DO_V, bool VNET>
     __device__ __forceinline__ void forward(const float (&obs)[6], float (&out)[4]) const
     {
-        if (VNET) net_forward16<OBS, NP, DO_P, DO_V, ETILES_>(obs, V, hs, half, out);
-        else net_forward16<OBS, NP, DO_P, DO_V, ETILES_>(obs, P, hs, half, out);
+        if (VNET) net_forward16<S, OBS, NP, DO_P, DO_V, ETILES_>(obs, V, hs, half, out);
+        else net_forward16<S, OBS, NP, DO_P, DO_V, ETILES_>(obs, P, hs, half, out);
     }
 };
 
@@ -646,8 +688,8 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 
 template <class Env, class Net> void launch_net(const RolloutArgs &a, unsigned grid, hipStream_t s)
 {
-    if (a.env.reset_draw) hipLaunchKernelGGL((k_rollout<Env, Net, true>), dim3(grid), dim3(ROLLOUT_BLOCK), 0, s, a, a.params);
-    else hipLaunchKernelGGL((k_rollout<Env, Net, false>), dim3(grid), dim3(ROLLOUT_BLOCK), 0, s, a, a.params);
+    if (a.env.reset_draw) PPO_LAUNCH((k_rollout<Env, Net, true>), dim3(grid), dim3(ROLLOUT_BLOCK), s, a, a.params);
+    else PPO_LAUNCH((k_rollout<Env, Net, false>), dim3(grid), dim3(ROLLOUT_BLOCK), s, a, a.params);
 }
 
 // Envs per wave for the f16-split nets: 64, or 32 when the batch is too small to give every SIMD of
@@ -662,17 +704,25 @@ template <class Env, int A> int launch_rollout(const RolloutArgs &a, int joint, 
         const int per_block = wave_envs * (ROLLOUT_BLOCK / 64);
         return (unsigned)((a.env.N + per_block - 1) / per_block);
     };
+    const bool half_waves = wave_envs ? wave_envs == 32 : a.env.N <= HALF_WAVE_MAX_ENVS;
     if (net_mode == PPO_NET_F32) {
         if (joint) launch_net<Env, NetF32<OBS, A, true>>(a, grid_for(64), s);
         else launch_net<Env, NetF32<OBS, A, false>>(a, grid_for(64), s);
-    } else {
-        const bool half_waves = wave_envs ? wave_envs == 32 : a.env.N <= HALF_WAVE_MAX_ENVS;
+    } else if (net_mode == PPO_NET_BF16X3) {
         if (half_waves) {
-            if (joint) launch_net<Env, NetF16<OBS, A, true, 1>>(a, grid_for(32), s);
-            else launch_net<Env, NetF16<OBS, A, false, 1>>(a, grid_for(32), s);
+            if (joint) launch_net<Env, NetF16<SchemeBF16, OBS, A, true, 1>>(a, grid_for(32), s);
+            else launch_net<Env, NetF16<SchemeBF16, OBS, A, false, 1>>(a, grid_for(32), s);
         } else {
-            if (joint) launch_net<Env, NetF16<OBS, A, true, 2>>(a, grid_for(64), s);
-            else launch_net<Env, NetF16<OBS, A, false, 2>>(a, grid_for(64), s);
+            if (joint) launch_net<Env, NetF16<SchemeBF16, OBS, A, true, 2>>(a, grid_for(64), s);
+            else launch_net<Env, NetF16<SchemeBF16, OBS, A, false, 2>>(a, grid_for(64), s);
+        }
+    } else {
+        if (half_waves) {
+            if (joint) launch_net<Env, NetF16<SchemeF16, OBS, A, true, 1>>(a, grid_for(32), s);
+            else launch_net<Env, NetF16<SchemeF16, OBS, A, false, 1>>(a, grid_for(32), s);
+        } else {
+            if (joint) launch_net<Env, NetF16<SchemeF16, OBS, A, true, 2>>(a, grid_for(64), s);
+            else launch_net<Env, NetF16<SchemeF16, OBS, A, false, 2>>(a, grid_for(64), s);
         }
     }
     return ppo_launch_status();
@@ -685,8 +735,8 @@ extern "C" {
 size_t ppo_rollout_param_floats(int kind, int joint, int net_mode)
 {
     const int obs = ppo_env_obs_dim(kind);
-    if (obs < 0 || (net_mode != PPO_NET_F32 && net_mode != PPO_NET_F16_SPLIT)) return 0;
-    const size_t bb = net_mode == PPO_NET_F32 ? (size_t)backbone_floats(obs) : (size_t)BB16_WORDS;
+    if (obs < 0 || (net_mode != PPO_NET_F32 && net_mode != PPO_NET_F16_SPLIT && net_mode != PPO_NET_BF16X3)) return 0;
+    const size_t bb = net_mode == PPO_NET_F32 ? (size_t)backbone_floats(obs) : (size_t)bb16_words(net_mode == PPO_NET_BF16X3 ? 3 : 2);
     return bb * (joint ? 1 : 2) + (size_t)HEAD_FLOATS;
 }
 
@@ -702,7 +752,7 @@ int ppo_rollout_fused_ex(int kind, double *state, int *elapsed, float *ep_ret, i
     PPO_REQUIRE(wave_envs == 0 || wave_envs == 32 || wave_envs == 64);
     PPO_REQUIRE(kind == PPO_ENV_CARTPOLE || kind == PPO_ENV_ACROBOT);
     PPO_REQUIRE(!reward_sum || ppo_aligned(reward_sum, 8));
-    PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT);
+    PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT || net_mode == PPO_NET_BF16X3);
     PPO_REQUIRE(N >= 0 && T >= 0);
     if (N == 0 || T == 0) return 0;
     PPO_REQUIRE(state && elapsed && ep_ret && ep_len && episode && params && obs_io && states && actions &&

@@ -449,7 +449,7 @@ template <int LEVEL, bool INCR = false>
 int sel_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N, const SelWs &w,
               double *stats5, unsigned blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_sel<LEVEL, INCR>), dim3(blocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5);
+    PPO_LAUNCH((k_sel<LEVEL, INCR>), dim3(blocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5);
     return ppo_launch_status();
 }
 
@@ -737,7 +737,7 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
     ib.shadow = reinterpret_cast<uint2 *>(p + incr_cnt_bytes(N));
     size_t iblocks = ((size_t)N + INCR_ENVS - 1) / INCR_ENVS;
     if (iblocks > 256) iblocks = 256;
-    hipLaunchKernelGGL(k_sel_incr, dim3((unsigned)iblocks), dim3(SEL_HBLOCK), 0, s, ret_ring, len_ring, ring_cnt, ring, N, w,
+    PPO_LAUNCH(k_sel_incr, dim3((unsigned)iblocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, w,
                        ib, stats5);
     int rc = ppo_launch_status();
     if (rc) return rc;

@@ -361,7 +361,12 @@ def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int
 
 
 # --------------------------------------------------------------------------- fused rollout
-NET_F32, NET_F16_SPLIT, NET_AUTO = 0, 1, 2   # include/ppo_amd.h: PPO_NET_F32, PPO_NET_F16_SPLIT; AUTO is resolved here
+NET_F32, NET_F16_SPLIT, NET_BF16X3 = 0, 1, 2   # include/ppo_amd.h: PPO_NET_F32, PPO_NET_F16_SPLIT, PPO_NET_BF16X3
+NET_AUTO = -1                                  # resolved here, never passed to the library
+NET_NAMES = {NET_F32: "f32", NET_F16_SPLIT: "f16_split", NET_BF16X3: "bf16x3", NET_AUTO: "auto"}
+# What NET_AUTO runs OUTSIDE the limits of the two-piece f16 split: the f32-grade three-piece bf16 kernels
+# (round 3; ~1.7x the speed of the f32-MFMA kernels at the same accuracy).  PPO_AMD_NET_FALLBACK=f32 keeps round 2's.
+NET_AUTO_FALLBACK = {"bf16x3": NET_BF16X3, "f32": NET_F32}[os.environ.get("PPO_AMD_NET_FALLBACK", "bf16x3")]
 # NET_AUTO: the split kernels run only for parameter sets inside these limits of
 # ppo_rollout_pack_params' split_diag (pack.hip says what the three numbers are;
 # tests/test_gpu_net_precision.py pins the limits against a float64 forward and PyTorch's f32 one)
@@ -393,7 +398,7 @@ def pack_dense_agent(agent, net_mode: int = NET_F32, out: torch.Tensor | None = 
     launch, no host work beyond the call.  net_mode is NET_F32 or NET_F16_SPLIT; diag_out (device
     f32[3]) receives split_diag, the accuracy indicators of the split mode for this parameter set."""
     lib = _lib.load()
-    assert net_mode in (NET_F32, NET_F16_SPLIT)
+    assert net_mode in (NET_F32, NET_F16_SPLIT, NET_BF16X3)
     pi = agent.pi_backbone
     w1 = pi[0].weight
     if not w1.is_cuda:
@@ -431,7 +436,7 @@ def resolve_net_mode(agent, net_mode: int):
     ok = split_ok(diag.tolist())
     if ok:
         return params, NET_F16_SPLIT, True
-    return pack_dense_agent(agent, NET_F32), NET_F32, False
+    return pack_dense_agent(agent, NET_AUTO_FALLBACK), NET_AUTO_FALLBACK, False
 
 
 def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, log_probs, values, rewards, done,
@@ -558,6 +563,31 @@ def clip_adam_supported(opt) -> bool:
                 or g.get("fused") or g.get("differentiable")) and not isinstance(g["lr"], torch.Tensor)
 
 
+_set_version_counter = getattr(getattr(torch._C, "_autograd", None), "_unsafe_set_version_counter", None)   # private torch API
+_param_generation = 0
+
+
+def param_generation() -> int:
+    """Number of in-place parameter updates made by this module's kernels (clip_adam_step) so far.
+    SyncVecEnv.prepack keys the packed rollout parameters on it as well as on the tensors' own version counters,
+    so a torch build without the private version-counter setter still repacks after every optimiser step."""
+    return _param_generation
+
+
+def _note_inplace_update(params):
+    """The parameters changed in place behind autograd's back: bump their version counters like an in-place
+    torch op would, where this torch build lets us (list form in 2.10, one tensor at a time in older builds)."""
+    global _param_generation
+    _param_generation += 1
+    if _set_version_counter is None:
+        return
+    try:
+        _set_version_counter(params, [p._version + 1 for p in params])
+    except TypeError:
+        for p in params:
+            _set_version_counter(p, p._version + 1)
+
+
 def clip_adam_step(opt, group: "GradGroup", max_grad_norm: float):
     """nn.utils.clip_grad_norm_(params of `group`, max_grad_norm); opt.step() for the (parameter, gradient)
     pairs of one dense_update_grads launch, as ONE kernel on the group's flat gradient bucket (reference
@@ -600,6 +630,4 @@ def clip_adam_step(opt, group: "GradGroup", max_grad_norm: float):
                                 float(max_grad_norm), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                 float(g["eps"]), step, _stream())
     _lib.check(rc, "ppo_clip_adam_step")
-    # the parameters changed in place behind autograd's back: bump their version counters like an in-place
-    # torch op would (SyncVecEnv.prepack keys the packed rollout parameters on them)
-    torch._C._autograd._unsafe_set_version_counter(params, [p._version + 1 for p in params])
+    _note_inplace_update(params)

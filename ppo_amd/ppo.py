@@ -203,18 +203,19 @@ class SyncVecEnv:
         # env transition) in ONE kernel launch.  False = PyTorch MLP + one env kernel per time step.
         self.fused_rollout = True
         # how the whole-rollout kernel multiplies inside the network (include/ppo_amd.h): exact f32
-        # MFMA products (ops.NET_F32), f16 MFMAs on two-piece splits (ops.NET_F16_SPLIT, ~1.9x faster,
-        # 22 bits per operand), or -- the default -- the split kernels whenever the pack kernel's
-        # split_diag says they are as accurate as f32 for the current parameters, f32 otherwise
-        # (ops.NET_AUTO).  PPO_AMD_NET = auto | f32 | f16_split.
-        self.net_mode = {"auto": ops.NET_AUTO, "f32": ops.NET_F32, "f16_split": ops.NET_F16_SPLIT}[
-            os.environ.get("PPO_AMD_NET", "auto")]
-        self.net_mode_used = None    # what the last whole-rollout launch ran (NET_F32 / NET_F16_SPLIT)
+        # MFMA products (ops.NET_F32), f16 MFMAs on two-piece splits (ops.NET_F16_SPLIT, ~2x faster,
+        # 22 bits per operand), bf16 MFMAs on three-piece splits (ops.NET_BF16X3: operands exact, f32-grade
+        # at every weight scale), or -- the default -- the f16-split kernels whenever the pack kernel's
+        # split_diag says they are as accurate as f32 for the current parameters, bf16x3 otherwise
+        # (ops.NET_AUTO).  PPO_AMD_NET = auto | f32 | f16_split | bf16x3.
+        self.net_mode = {"auto": ops.NET_AUTO, "f32": ops.NET_F32, "f16_split": ops.NET_F16_SPLIT,
+                         "bf16x3": ops.NET_BF16X3}[os.environ.get("PPO_AMD_NET", "auto")]
+        self.net_mode_used = None    # what the last whole-rollout launch ran (NET_F32 / NET_F16_SPLIT / NET_BF16X3)
         self._pack = None            # parameters packed for the rollout kernel, see _net()
         self.wave_envs = 0           # tests / tuning: force 32 or 64 envs per wave (0 = the library chooses by N)
         self._rollouts = 0
         self._bufset = None           # see _alloc
-        self._params = None           # list(agent.parameters()), see prepack
+        self._params = None           # (module._parameters dict, name) per parameter of the agent, see prepack
 
         first = env_fn()
         self.native = isinstance(first, ppo_envs.DeviceEnv)
@@ -383,9 +384,13 @@ class SyncVecEnv:
         host synchronisation.  PPO.train_step calls this right behind the last optimizer.step() of an
         update, so that the next rollout starts with its parameters packed.  Returns the device f32[3]
         split_diag still to be read (ops.NET_AUTO), else None."""
-        if self._params is None:                           # walking the module tree costs ~10 us per call
-            self._params = list(self.agent.parameters())
-        key = (self.net_mode,) + tuple([p._version for p in self._params])
+        if self._params is None:                           # walking the module tree costs ~10 us per call: keep the slots
+            self._params = [(m._parameters, n) for m in self.agent.modules() for n, v in m._parameters.items() if v is not None]
+        # (_version: every in-place torch update; param_generation: every ppo_clip_adam_step; data_ptr: a parameter
+        # re-created (the slot is looked up again each time), moved by module.to() or rewritten through `.data =`,
+        # none of which bump _version)
+        key = (self.net_mode, ops.param_generation()) + tuple([(p._version, p.data_ptr()) for p in
+                                                               [d[n] for d, n in self._params]])
         pk = self._pack
         if pk is not None and pk["key"] == key:
             return pk["diag"] if pk["ok"] is None else None
@@ -394,7 +399,7 @@ class SyncVecEnv:
             if self.net_mode == ops.NET_AUTO:
                 pk["diag"] = torch.empty(3, dtype=torch.float32, device=self.kdev)
         pk["key"] = key
-        modes = (ops.NET_F16_SPLIT, ops.NET_F32) if self.net_mode == ops.NET_AUTO else (self.net_mode,)
+        modes = (ops.NET_F16_SPLIT, ops.NET_AUTO_FALLBACK) if self.net_mode == ops.NET_AUTO else (self.net_mode,)
         for m in modes:                                    # AUTO: both layouts (two 5 us launches), decided below
             pk["bufs"][m] = ops.pack_dense_agent(self.agent, m, out=pk["bufs"].get(m),
                                                  diag_out=pk["diag"] if m == ops.NET_F16_SPLIT else None)
@@ -413,7 +418,7 @@ class SyncVecEnv:
         pk = self._pack
         if self.net_mode != ops.NET_AUTO:
             return pk["bufs"][self.net_mode], self.net_mode
-        mode = ops.NET_F16_SPLIT if pk["ok"] else ops.NET_F32
+        mode = ops.NET_F16_SPLIT if pk["ok"] else ops.NET_AUTO_FALLBACK
         return pk["bufs"][mode], mode
 
     def _locate_end_states(self):
@@ -513,6 +518,11 @@ class SyncVecEnv:
                 fn(np.asarray(host[at:at + n], dtype=np.float64))
                 at += n
         return (parts[0] if len(parts) == 1 else torch.cat(parts)), take
+
+    @property
+    def local_max_ep_return(self):
+        """Running max over THIS rank's envs only (max_ep_return is job-wide under data parallelism)."""
+        return self._stat("max")
 
     max_ep_return = property(lambda self: self._stat("max"),
                              lambda self, v: self._stats_host.__setitem__("max", v))
@@ -903,6 +913,8 @@ class PPO:
             "metrics/ep_return_max": ep_return_max,
             "metrics/ep_length_0.50": float(ve.median_ep_length),
         }
+        if ve.native and ve.net_mode_used is not None:     # (an addition: which network arithmetic this update's rollout ran)
+            self.last_metrics["utils/net_mode_used"] = ops.NET_NAMES[ve.net_mode_used]
         self._log(self.last_metrics, step=self.updates * steps_per_env * num_envs * world)
         return policy_loss, critic_loss, entropy, clip_frac, kl_div, rollout_return, ep_return_max
 
@@ -1019,10 +1031,13 @@ class PPO:
                                   "clip_frac": f"{clip_frac:.3f}"}, refresh=False)
                 # (refresh=False: the bar redraws at tqdm's own rate limit, 10 Hz, instead of once per update --
                 # a forced redraw is ~0.1 ms of host time between two updates while the device waits)
-            if early_stop_reward is not None and ep_return_max >= early_stop_reward:
+            # reference :758.  Data parallel: the decision is taken by ALL ranks together (MAX all-reduce) -- a rank
+            # that left the loop alone would leave the others waiting in the next update's first collective.
+            if early_stop_reward is not None and ppo_dist.any_rank(ep_return_max >= early_stop_reward, "early_stop_reward"):
                 if pbar is not None:
                     pbar.close()
-                print("Early stop reward reached.")
+                if rank == 0:
+                    print("Early stop reward reached.")
                 break
 
 

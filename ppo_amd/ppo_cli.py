@@ -4,9 +4,11 @@
         <num_epochs> <batch_size> <critic_coef> <entropy_coef> <clip_ratio> <max_grad_norm>
         <learning_rate> <discount_factor> <gae_factor> <norm_adv> <clip_va_loss> <conv_net>
         <joint_network> [--use_gpu 1] [--target_div F] [--render_every N] [--render_fps F]
-        [--early_stop_reward F] [--checkpoint_path P --checkpoint_every N] [--resume_from P]
+        [--early_stop_reward F] [--checkpoint_path P --checkpoint_every N] [--resume_from P] [--gpus N]
 
-The last three options are additions (the reference keeps no checkpoints).
+The last four options are additions (the reference keeps no checkpoints and is a single process).  --gpus N > 1
+started as one plain process becomes N data-parallel ranks, one per GPU (ppo_amd/launch.py; the same thing
+`torchrun --nproc-per-node N -m ppo_amd.ppo_cli ...` does): num_envs and batch_size stay GLOBAL numbers.
 
 `env_module` is looked up first as given (the reference's behaviour: any importable module
 with a `train_fn`), then inside this package (env_cartpole, env_acrobot).  Under torchrun
@@ -14,8 +16,11 @@ the run is data-parallel over the launched ranks.
 """
 import argparse
 import importlib
+import os
+import sys
 
 from . import dist as ppo_dist
+from . import launch
 from .ppo import PPO
 
 _POSITIONAL = [
@@ -39,6 +44,7 @@ def build_parser():
     p.add_argument("--checkpoint_path", default=None, type=str)
     p.add_argument("--checkpoint_every", default=0, type=int)
     p.add_argument("--resume_from", default=None, type=str)
+    p.add_argument("--gpus", default=1, type=int)
     return p
 
 
@@ -52,6 +58,12 @@ def resolve_env_fn(name: str):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if launch.needs_self_launch(args.gpus):            # before anything touches the GPU
+        launch.check_gpu_count(args.gpus, os.environ.get("PPO_AMD_DIST_BACKEND") or "nccl", f"ppo_cli --gpus {args.gpus}")
+        sys.exit(launch.self_launch(args.gpus, [sys.executable, "-m", "ppo_amd.ppo_cli"]
+                                    + list(sys.argv[1:] if argv is None else argv)))
+    if launch.under_launcher() and args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"ppo_cli: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     print()
     ppo_dist.init_from_env()
     env_fn = resolve_env_fn(args.env_module)

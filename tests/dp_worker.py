@@ -18,12 +18,16 @@ def main():
     out, num_envs, T, batch, updates = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     kind = sys.argv[6] if len(sys.argv) > 6 else "cartpole"
     joint = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+    early_stop_reward = float(sys.argv[8]) if len(sys.argv) > 8 and sys.argv[8] != "none" else None
+    if os.environ.get("PPO_AMD_DP_WATCHDOG"):      # where is this rank when the job hangs?  (every thread's stack, then exit)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PPO_AMD_DP_WATCHDOG"]), exit=True)
     train_fn = lambda: DeviceEnv(kind)  # noqa: E731
     D.init_from_env()                       # backend from PPO_AMD_DIST_BACKEND (gloo: both ranks share the one GPU)
     rank, world = D.rank(), D.world_size()
     torch.manual_seed(100 + 7 * rank)       # different init per rank: broadcast_params must equalise
     ppo = PPO(0.99, 0.95, 1, 1, 0, joint, True, seed=2025)
-    rec = {"world": world, "rank": rank, "steps": [], "buffers": None, "init": None, "metrics": []}
+    rec = {"world": world, "rank": rank, "steps": [], "buffers": None, "init": None, "metrics": [], "local_max": []}
 
     def hook(info):
         ve = ppo.vec_env
@@ -45,13 +49,16 @@ def main():
             rec["init"] = {n: v.detach().cpu().clone() for n, v in ppo.agent.state_dict().items()}
             torch.manual_seed(555)          # same minibatch permutations in every run and on every rank
         r = orig(*a, **k)
-        rec["metrics"].append(dict(ppo.last_metrics))
+        rec["metrics"].append({k_: v for k_, v in ppo.last_metrics.items() if not isinstance(v, str)})
+        rec["local_max"].append(float(ppo.vec_env.local_max_ep_return))   # this rank's OWN shard (the logged one is job-wide)
         return r
 
     ppo.train_step = train_step
     ppo.train(train_fn, num_updates=updates, num_envs=num_envs, steps_per_env=T, num_epochs=2, batch_size=batch,
               critic_coef=0.5, entropy_coef=0.01, clip_ratio=0.2, max_grad_norm=0.5, learning_rate=3e-4,
-              target_div=0.05)
+              target_div=0.05, early_stop_reward=early_stop_reward)
+    rec["updates_done"] = ppo.updates
+    rec["collectives"] = D.sequence_number()
     torch.save(rec, f"{out}.rank{rank}")
     if world > 1:
         torch.distributed.barrier()

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("obs,actions,joint", [(4, 2, 1), (4, 2, 0), (6, 3, 1), (6, 3, 0)])
-@pytest.mark.parametrize("net_mode", [0, 1], ids=["f32", "f16_split"])
+@pytest.mark.parametrize("net_mode", [0, 1, 2], ids=["f32", "f16_split", "bf16x3"])
 def test_pack_kernel_equals_the_layout_definition(obs, actions, joint, net_mode):
     from ppo_amd import ops, spaces
     from ppo_amd.ppo import Agent
@@ -55,9 +55,9 @@ def test_split_diag_follows_its_definition():
             agent.va_backbone[2].weight.mul_(scale)
         ops.pack_dense_agent(agent, ops.NET_F16_SPLIT, diag_out=diag)
         assert np.allclose(diag.tolist(), want(), rtol=1e-5)
-    assert diag.tolist()[2] > ops.SPLIT_ROWNORM2_MAX             # large value-backbone weights: auto must pick f32
+    assert diag.tolist()[2] > ops.SPLIT_ROWNORM2_MAX             # large value-backbone weights: auto must leave the f16 split (for the f32-grade bf16x3 kernels)
     _, mode, ok = ops.resolve_net_mode(agent, ops.NET_AUTO)
-    assert mode == ops.NET_F32 and ok is False
+    assert mode == ops.NET_AUTO_FALLBACK == ops.NET_BF16X3 and ok is False
     torch.manual_seed(2)
     fresh = Agent(spaces.Box(-np.inf, np.inf, (6,)), spaces.Discrete(3), 0, 1, "cuda")
     _, mode, ok = ops.resolve_net_mode(fresh, ops.NET_AUTO)

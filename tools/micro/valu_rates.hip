@@ -21,6 +21,10 @@ template <int KIND> __global__ void k(float *out, int iters, float seed, long lo
             if (KIND == 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i]));
             if (KIND == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
             if (KIND == 5) asm volatile("v_cvt_pk_f16_f32 %0, %0, %0" : "+v"(v[i]));
+            if (KIND == 6) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %0" : "+v"(v[i]));
+            if (KIND == 7) asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(v[i]) : "v"(v[(i + 1) % REP]));
+            if (KIND == 8) asm volatile("v_perm_b32 %0, %0, %0, %1" : "+v"(v[i]) : "v"(0x07060302));
+            if (KIND == 9) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(v[i]));
         }
       }
 #pragma unroll
@@ -74,5 +78,10 @@ int main()
                run<1>("v_rcp_f32", REP, out) / f, run<2>("v_exp_f32", REP, out) / f, run<3>("v_pk_fma_f32", REP / 2, out) / f,
                run<4>("v_fma_f64", REP / 2, out) / f, run<5>("v_cvt_pk_f16_f32", REP, out) / f);
     }
+    g_threads = 256;
+    const double f = run<0>("v_fma_f32", REP, out);
+    printf("  (round 3, one wave per SIMD) cvt_pk_bf16/fma %.2f  dot2c_f32_bf16/fma %.2f  perm_b32/fma %.2f  and_b32/fma %.2f\n",
+           run<6>("v_cvt_pk_bf16_f32", REP, out) / f, run<7>("v_dot2c_f32_bf16", REP, out) / f,
+           run<8>("v_perm_b32", REP, out) / f, run<9>("v_and_b32", REP, out) / f);
     return 0;
 }

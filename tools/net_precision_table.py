@@ -1,7 +1,9 @@
 """Error of the whole-rollout kernel's network forward against float64, per backbone weight scale:
-forced f16-split, exact-f32 MFMA and PyTorch's f32 forward, with the pack kernel's split margin
-(calibrates ops.SPLIT_MARGIN_MIN; asserted in tests/test_gpu_net_precision.py).
-    python tools/net_precision_table.py > profiles/r02_net_precision.txt"""
+forced f16-split, three-piece bf16 (PPO_NET_BF16X3), exact-f32 MFMA and PyTorch's f32 forward, with the pack
+kernel's split margin (calibrates ops.split_ok; asserted in tests/test_gpu_net_precision.py).  Max abs error
+over 2^18 states for each, and the rms error of the value head for the two f32-grade kernels (the maximum of
+2^18 draws is a noisy statistic; the rms is not).
+    python tools/net_precision_table.py > profiles/r03_net_precision.txt"""
 import os
 import sys
 
@@ -13,7 +15,7 @@ import test_gpu_net_precision as T
 from ppo_amd import Agent, ops
 from ppo_amd.envs import DeviceEnv
 
-print("kind joint scale head | floor margin, rms row norm W1', W2' | split: v lp | f32 mfma: v lp | torch f32: v lp   (max abs error over 2^18 states)")
+print("kind joint scale head | floor margin, rms row norm W1', W2' | split: v lp | bf16x3: v lp | f32 mfma: v lp | torch f32: v lp   (max abs error over 2^18 states) | rms v: bf16x3 f32mfma torch")
 for kind in ("cartpole", "acrobot"):
     gen = torch.Generator(device="cuda").manual_seed(11)
     states = T._states(kind, T.NSTATES, gen)
@@ -33,14 +35,18 @@ for kind in ("cartpole", "acrobot"):
                 diag = torch.empty(3, device="cuda")
                 ops.pack_dense_agent(agent, ops.NET_F16_SPLIT, diag_out=diag)
                 dg = diag.tolist()
-                out = []
-                for mode in (ops.NET_F16_SPLIT, ops.NET_F32):
+                out, rms = [], []
+                for mode in (ops.NET_F16_SPLIT, ops.NET_BF16X3, ops.NET_F32):
                     v, act, lp, _ = T._kernel_forward(kind, agent, states, mode)
                     v64, lp64 = T._f64(agent, states, act)
                     out += [float((v.double() - v64).abs().max()), float((lp.double() - lp64).abs().max())]
+                    if mode != ops.NET_F16_SPLIT:
+                        rms.append(float((v.double() - v64).pow(2).mean().sqrt()))
                 act = torch.zeros(T.NSTATES, dtype=torch.int32, device="cuda")
                 v64, lp64 = T._f64(agent, states, act)
                 vt, lpt = T._f32_torch(agent, states, act)
                 out += [float((vt.double() - v64).abs().max()), float((lpt.double() - lp64).abs().max())]
+                rms.append(float((vt.double() - v64).pow(2).mean().sqrt()))
                 print(f"{kind:8s} {joint} {scale:7.1e} {head_gain:4.0f} | {dg[0]:8.3g} {dg[1]:6.2f} {dg[2]:6.2f} | "
-                      + " | ".join(f"{out[i]:.2e} {out[i+1]:.2e}" for i in (0, 2, 4)), flush=True)
+                      + " | ".join(f"{out[i]:.2e} {out[i+1]:.2e}" for i in (0, 2, 4, 6))
+                      + " | " + " ".join(f"{x:.2e}" for x in rms), flush=True)
