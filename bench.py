@@ -251,7 +251,7 @@ def main():
                 ev_dense = ve._ev_dense
             else:
                 ev_dense = ppo._scatter_end_values(ve, agent.get_values(ve.end_states))
-            record = record and len(gae_events) < 256   # the timed entry has 256 event slots
+            record = record and len(gae_events) < 128   # event slots 0..127 (128.. are the step breakdown's)
             # hipExtLaunchKernelGGL start/stop events on the GAE dispatch itself (ppo_gae_dense_timed in
             # csrc/gae.hip); read back after the timed region.  Agrees with rocprofv3 --kernel-trace.
             slot = len(gae_events) if record else None
@@ -350,11 +350,11 @@ def main():
         hot_path_step(False)
     per_kernel = []
     for k in range(16):
-        _lib.check(lib.ppo_prof_arm(5 * k, 5), "ppo_prof_arm")
+        _lib.check(lib.ppo_prof_arm(128 + 5 * k, 5), "ppo_prof_arm")
         hot_path_step(False)
     _lib.check(lib.ppo_prof_arm(0, 0), "ppo_prof_arm")
     torch.cuda.synchronize()
-    per_kernel = np.array([[slot_us(5 * k + j) for j in range(5)] for k in range(4, 16)])   # (first four: settle)
+    per_kernel = np.array([[slot_us(128 + 5 * k + j) for j in range(5)] for k in range(4, 16)])   # (first four: settle)
     stats_us, ro_us, gae_bd_us = per_kernel[:, :3].sum(1).mean(), per_kernel[:, 3].mean(), per_kernel[:, 4].mean()
     ro_ms = float(ro_us) * 1e-3
     waves = (N + 63) // 64 if N > 32768 else (N + 31) // 32          # 64- or 32-env waves (csrc/rollout.hip)

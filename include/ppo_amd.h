@@ -332,7 +332,7 @@ int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w
  *   reward_sum  device f64 or NULL: the sum of all T*N rewards is ADDED to it (the caller zeroes
  *   it) -- SyncVecEnv.total_return (src/ppo.py:318, :348); per-env f32 sums over time, f64 across envs
  * Env state arguments and rings as in ppo_env_step; row T-1 gets the forced truncation.
- * net_mode: PPO_NET_F32, PPO_NET_F16_SPLIT or PPO_NET_BF16X3; `params` must have been packed for that mode.
+ * net_mode: one of the three PPO_NET_* modes; `params` must have been packed for that mode.
  * Values / log-probs agree with the PyTorch f32 forward of the same parameters to ~1e-6 (different
  * summation order than hipBLASLt; the split mode keeps 22 bits per operand), not bit for bit.
  */

@@ -157,6 +157,18 @@ def div_by_total_mass_mismatches(n, seed=0, e_lo=-40, e_hi=20):
     return int(f(C.c_long(n), C.c_uint64(seed), C.c_int(e_lo), C.c_int(e_hi)))
 
 
+def acrobot_terminal(state):
+    """(flags int32 [n], lhs float64 [n]) of gymnasium's AcrobotEnv._terminal, -cos(s0) - cos(s1 + s0) > 1.0, for
+    float64 states [n, 4] (glibc cos)."""
+    st = np.ascontiguousarray(state, dtype=np.float64)
+    n = st.shape[0]
+    flags, lhs = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float64)
+    f = lib().oracle_acrobot_terminal
+    f.restype = C.c_int
+    f(_p(st, C.c_double), C.c_long(n), _p(flags, C.c_int), _p(lhs, C.c_double))
+    return flags, lhs
+
+
 def shuffle_indices(n, seed, stream_id):
     """The permutation ppo_shuffle_indices makes (oracle_shuffle_indices), as int64 [n]."""
     out = np.empty(n, np.int64)

@@ -40,7 +40,7 @@ def _mfma_frags(weight: torch.Tensor, bias: torch.Tensor, chained: bool = False)
     return frag.reshape(-1)
 
 
-NET_F32, NET_F16_SPLIT, NET_BF16X3 = 0, 1, 2      # include/ppo_amd.h: PPO_NET_F32, PPO_NET_F16_SPLIT, PPO_NET_BF16X3
+NET_F32, NET_F16_SPLIT, NET_BF16X3 = 0, 1, 2      # include/ppo_amd.h: PPO_NET_*
 _TANH_SCALE = 2.0 * 1.4426950408889634   # 2 log2(e): tanh(x) = 1 - 2 / (exp2(_TANH_SCALE x) + 1)
 
 

@@ -460,6 +460,21 @@ void oracle_acrobot_reset(double *state4, int *elapsed, float *obs6, const doubl
     *elapsed = 0;
 }
 
+/* AcrobotEnv._terminal: bool(-cos(s[0]) - cos(s[1] + s[0]) > 1.0), for n states [n,4]; returns the flag of the
+ * first state; flags / lhs (the left-hand side) may be NULL. */
+int oracle_acrobot_terminal(const double *state, long n, int *flags, double *lhs)
+{
+    int first = 0;
+    for (long i = 0; i < n; ++i) {
+        const double *s = state + 4 * i;
+        const double v = -cos(s[0]) - cos(s[1] + s[0]);
+        if (lhs) lhs[i] = v;
+        if (flags) flags[i] = v > 1.0;
+        if (i == 0) first = v > 1.0;
+    }
+    return first;
+}
+
 int oracle_acrobot_step(double *state4, int *elapsed, int action, float *obs6, float *reward)
 {
     const double dt = 0.2 - 0;
@@ -482,7 +497,7 @@ int oracle_acrobot_step(double *state4, int *elapsed, int action, float *obs6, f
     ns[2] = acrobot_bound(ns[2], -4 * M_PI, 4 * M_PI);
     ns[3] = acrobot_bound(ns[3], -9 * M_PI, 9 * M_PI);
     for (int i = 0; i < 4; ++i) state4[i] = ns[i];
-    int terminated = (-cos(ns[0]) - cos(ns[1] + ns[0]) > 1.0);
+    int terminated = oracle_acrobot_terminal(ns, 1, NULL, NULL);
     *reward = terminated ? 0.0f : -1.0f;
     oracle_acrobot_obs(state4, obs6, 0);
     *elapsed += 1;

@@ -69,6 +69,34 @@ __global__ void __launch_bounds__(256) k_categorical_sample(const float *logits,
     logp[n] = lp;
 }
 
+// ---- test hooks (private; tests/test_gpu_env.py): pieces of the Acrobot transition on caller-made operands ----
+// flag[i] = Acrobot::terminal of state[i] (what the step kernels decide after a transition); lhs[i] = the value the
+// kernel's fast path compares with 1.0 (cos(theta1 + theta2) by the angle-sum identity)
+__global__ void __launch_bounds__(256) k_test_acrobot_terminal(const double *state, int *flag, double *lhs, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long j = i < n ? i : n - 1;                   // every lane runs (the guard band's branch is wave-uniform)
+    const double s[4] = {state[4 * j], state[4 * j + 1], state[4 * j + 2], state[4 * j + 3]};
+    const Acrobot::Trig t = Acrobot::trig_of(s[0], s[1]);
+    const bool term = Acrobot::terminal(s, t);
+    if (i < n) {
+        flag[i] = term ? 1 : 0;
+        lhs[i] = -t.c1 - __builtin_fma(t.c1, t.c2, -(t.s1 * t.s2));
+    }
+}
+
+// q_fast[i] = Acrobot::quot(num[i], den[i], Acrobot::recip(den[i])) -- the division the RK4 stages use --
+// and q_ieee[i] = num[i] / den[i] as the compiler's IEEE division sequence computes it
+__global__ void __launch_bounds__(256) k_test_acrobot_quot(const double *num, const double *den, double *q_fast,
+                                                           double *q_ieee, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = num[i], d = den[i];
+    q_fast[i] = Acrobot::quot(a, d, Acrobot::recip(d));
+    q_ieee[i] = a / d;
+}
+
 int env_dispatch(int kind, bool is_reset, const EnvArgs &a, hipStream_t s)
 {
     const int block = 256;
@@ -128,6 +156,22 @@ int ppo_env_step(int kind, double *state, int *elapsed, float *ep_ret, int *ep_l
     a.ret_ring = ret_ring; a.len_ring = len_ring; a.ring_cnt = ring_cnt; a.ring = ring; a.N = N;
     a.is_last = is_last;
     return env_dispatch(kind, false, a, (hipStream_t)stream);
+}
+
+int ppo_test_acrobot_terminal(const double *state, int *flag, double *lhs, long n, void *stream)
+{
+    PPO_REQUIRE(state && flag && lhs && n > 0);
+    hipLaunchKernelGGL(k_test_acrobot_terminal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       state, flag, lhs, n);
+    return ppo_launch_status();
+}
+
+int ppo_test_acrobot_quot(const double *num, const double *den, double *q_fast, double *q_ieee, long n, void *stream)
+{
+    PPO_REQUIRE(num && den && q_fast && q_ieee && n > 0);
+    hipLaunchKernelGGL(k_test_acrobot_quot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       num, den, q_fast, q_ieee, n);
+    return ppo_launch_status();
 }
 
 int ppo_categorical_sample(const float *logits, int A, uint64_t seed, uint64_t env_base, uint64_t step,

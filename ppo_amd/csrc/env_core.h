@@ -222,8 +222,24 @@ struct Acrobot {
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = ns[i];
         const Trig t = aux = write_obs(s, obs);
-        const bool terminated = (-t.c1 - __builtin_fma(t.c1, t.c2, -(t.s1 * t.s2)) > 1.0);   // cos(ns[1] + ns[0])
+        const bool terminated = terminal(s, t);
         reward = terminated ? 0.0f : -1.0f;
+        return terminated;
+    }
+
+    // gymnasium's termination test, bool(-cos(s[0]) - cos(s[1] + s[0]) > 1.0).  cos(theta1 + theta2) from the
+    // observation's own sin / cos (angle-sum identity) saves a trigonometric reduction per step and agrees with
+    // the direct value to a few 1e-16 -- so the identity DECIDES only where it cannot be wrong: outside a band of
+    // 1e-9 around the threshold, a million times its worst-case error.  Inside the band the reference's own
+    // expression is evaluated, so the flag is, structurally, that expression's (wave-uniform branch; taken by
+    // about one step in 10^9).
+    __device__ static bool terminal(const double (&s)[4], const Trig &t)
+    {
+        const double lhs = -t.c1 - __builtin_fma(t.c1, t.c2, -(t.s1 * t.s2));
+        bool terminated = lhs > 1.0;
+        if (__any(fabs(lhs - 1.0) < 1e-9)) {
+            if (fabs(lhs - 1.0) < 1e-9) terminated = (-cos(s[0]) - cos(s[1] + s[0]) > 1.0);
+        }
         return terminated;
     }
 };

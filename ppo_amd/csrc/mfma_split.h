@@ -52,15 +52,33 @@ __device__ __forceinline__ uint32_t pack_bf16(float a0, float a1)
     return __builtin_bit_cast(uint32_t, bf2{(__bf16)a0, (__bf16)a1});      // v_cvt_pk_bf16_f32, round to nearest even
 }
 
-__device__ __forceinline__ void split3_bf16(float a0, float a1, uint32_t &p0, uint32_t &p1, uint32_t &p2)
+// r = x - (piece `hi ? upper : lower` of the packed pair p), exact.  Both operands reach the builtin through
+// registers the compiler cannot see through: hipcc 7.2 folds a CONSTANT bf16 pair -- the selector (-1, 0), or the
+// packed pieces of a constant input such as the 1.0 that carries the bias -- into an inline operand (-1.0, 1.0),
+// which the hardware does not read as that pair (tools/micro/bf16x3_probe.hip: every lower-half value wrong;
+// in the kernel: wrong biases).  And v_dot2c_f32_bf16 written as inline asm loses the wait states the compiler
+// inserts between the v_cvt_pk_bf16_f32 that makes p and the dot instruction that reads it (same probe).
+struct Bf16Select {
+    uint32_t lo, hi;       // bf16 pairs (-1, 0) and (0, -1), in scalar registers, made once per kernel
+    __device__ __forceinline__ void init()
+    {
+        asm volatile("s_mov_b32 %0, 0xbf80" : "=s"(lo));
+        asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(hi));
+    }
+};
+
+__device__ __forceinline__ float residual_bf16(float x, uint32_t p, uint32_t sel)
 {
-    const bf2 take_lo = {(__bf16)-1.0f, (__bf16)0.0f}, take_hi = {(__bf16)0.0f, (__bf16)-1.0f};
+    if (__builtin_constant_p(p)) asm("" : "+v"(p));        // (no instruction: hides a constant p from the folder)
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p), __builtin_bit_cast(bf2, sel), x, false);
+}
+
+__device__ __forceinline__ void split3_bf16(float a0, float a1, const Bf16Select &sel, uint32_t &p0, uint32_t &p1, uint32_t &p2)
+{
     p0 = pack_bf16(a0, a1);
-    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p0), take_lo, a0, false);
-    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p0), take_hi, a1, false);
+    const float r0 = residual_bf16(a0, p0, sel.lo), r1 = residual_bf16(a1, p0, sel.hi);
     p1 = pack_bf16(r0, r1);
-    const float s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p1), take_lo, r0, false);
-    const float s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p1), take_hi, r1, false);
+    const float s0 = residual_bf16(r0, p1, sel.lo), s1 = residual_bf16(r1, p1, sel.hi);
     p2 = pack_bf16(s0, s1);
 }
 

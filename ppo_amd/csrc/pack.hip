@@ -209,7 +209,7 @@ int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w
 {
     const int obs = ppo_env_obs_dim(kind);
     PPO_REQUIRE(obs > 0 && obs < 8 && obs % 2 == 0);
-    PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT || net_mode == PPO_NET_BF16X3);
+    PPO_REQUIRE(net_mode >= PPO_NET_F32 && net_mode <= PPO_NET_BF16X3);
     PPO_REQUIRE(pi_w1 && pi_b1 && pi_w2 && pi_b2 && policy_w && policy_b && critic_w && critic_b && params_out);
     PPO_REQUIRE(joint || (va_w1 && va_b1 && va_w2 && va_b2));
     PackArgs a{};
@@ -218,7 +218,7 @@ int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w
     a.policy_w = policy_w; a.policy_b = policy_b; a.critic_w = critic_w; a.critic_b = critic_b;
     a.out = params_out; a.split_diag = split_diag;
     a.obs = obs; a.A = kind == PPO_ENV_CARTPOLE ? 2 : 3; a.joint = joint ? 1 : 0; a.net_mode = net_mode;
-    a.bb_words = net_mode == PPO_NET_F32 ? backbone_floats(obs) : bb16_words(net_mode == PPO_NET_BF16X3 ? 3 : 2);
+    a.bb_words = net_mode == PPO_NET_F32 ? backbone_floats(obs) : bb16_words(net_mode == PPO_NET_F16_SPLIT ? 2 : 3);
     a.total_words = a.bb_words * (joint ? 1 : 2) + HEAD_FLOATS;
     const unsigned grid = (unsigned)((a.total_words + PACK_BLOCK - 1) / PACK_BLOCK) + 1u;   // + the margin block
     hipLaunchKernelGGL(k_pack_params, dim3(grid), dim3(PACK_BLOCK), 0, (hipStream_t)stream, a);

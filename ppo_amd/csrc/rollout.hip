@@ -310,17 +310,19 @@ __device__ __forceinline__ f32x2 tanh2v_prescaled(float x0, float x1)
 // Layouts as in mode 1 with three pieces instead of two (W1[op][piece 3][lane][4], W2[j][op][piece 3][lane][4]).
 struct SchemeF16 {          // mode 1: two f16 pieces, three terms
     static constexpr int P = 2, NT = 3;
+    struct Ctx { __device__ __forceinline__ void init() {} };
     __device__ static constexpr int tw(int t) { return t == 0 ? 1 : 0; }      // weight piece of term t
     __device__ static constexpr int ta(int t) { return t == 1 ? 1 : 0; }      // activation piece of term t
     __device__ static __forceinline__ f32x16 mfma(const Frag16 &a, const Frag16 &b, f32x16 c) { return mfma16(a, b, c); }
-    __device__ static __forceinline__ void split(float a0, float a1, uint32_t (&p)[2]) { split2(a0, a1, p[0], p[1]); }
+    __device__ static __forceinline__ void split(float a0, float a1, const Ctx &, uint32_t (&p)[2]) { split2(a0, a1, p[0], p[1]); }
 };
 struct SchemeBF16 {         // mode 2: three bf16 pieces, six terms, ascending magnitude
     static constexpr int P = 3, NT = 6;
+    using Ctx = Bf16Select;
     __device__ static constexpr int tw(int t) { return t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0; }   // w2 a0, w1 a1, w0 a2, w1 a0, w0 a1, w0 a0
     __device__ static constexpr int ta(int t) { return t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0; }
     __device__ static __forceinline__ f32x16 mfma(const Frag16 &a, const Frag16 &b, f32x16 c) { return mfma16_bf16(a, b, c); }
-    __device__ static __forceinline__ void split(float a0, float a1, uint32_t (&p)[3]) { split3_bf16(a0, a1, p[0], p[1], p[2]); }
+    __device__ static __forceinline__ void split(float a0, float a1, const Ctx &c, uint32_t (&p)[3]) { split3_bf16(a0, a1, c, p[0], p[1], p[2]); }
 };
 
 template <int P> struct RegW16 {
@@ -391,7 +393,7 @@ struct LdsHL {
 // logit rows (NetF16::load): softmax and sampling only depend on l1 - l0.
 template <class S, int OBS, int NP, bool DO_P, bool DO_V, int ETILES, class W, class HLT>
 __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w, const HLT &hl, int half,
-                                              float (&out)[4])
+                                              const typename S::Ctx &ctx, float (&out)[4])
 {
     constexpr int A = NP, P = S::P;
     static_assert(OBS < 8, "layer-1 inputs and the bias slot must fit one 8-wide k half");
@@ -403,7 +405,7 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint32_t pc[P];
-        S::split(in[2 * i], in[2 * i + 1], pc);
+        S::split(in[2 * i], in[2 * i + 1], ctx, pc);
 #pragma unroll
         for (int q = 0; q < P; ++q) ip[q].w[i] = pc[q];
     }
@@ -425,7 +427,7 @@ __device__ __forceinline__ void net_forward16(const float (&obs)[6], const W &w,
                 float a0, a1;
                 tanh2_prescaled(m[r], m[r + 1], a0, a1);
                 uint32_t pc[P];
-                S::split(a0, a1, pc);
+                S::split(a0, a1, ctx, pc);
 #pragma unroll
                 for (int q = 0; q < P; ++q) b2[q][e][2 * o + (r >> 3)].w[(r & 7) >> 1] = pc[q];
             }
@@ -513,6 +515,7 @@ template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     RegW16<S::P> P;
     LdsW16<S::P> V;
     LdsHL hs;
+    typename S::Ctx ctx;
     float bias4[4];
     int half;
 
@@ -522,6 +525,7 @@ template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     __device__ __forceinline__ void load(const float *__restrict__ params, float *smem, int lane)
     {
         half = lane >> 5;
+        ctx.init();
         P.load(params, lane);
         const float *heads = params + BB16_WORDS * (JOINT ? 1 : 2);
         float *shl = smem + (JOINT ? 0 : BB16_WORDS);
@@ -545,8 +549,8 @@ template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     template <bool DO_P, bool DO_V, bool VNET>
     __device__ __forceinline__ void forward(const float (&obs)[6], float (&out)[4]) const
     {
-        if (VNET) net_forward16<S, OBS, NP, DO_P, DO_V, ETILES_>(obs, V, hs, half, out);
-        else net_forward16<S, OBS, NP, DO_P, DO_V, ETILES_>(obs, P, hs, half, out);
+        if (VNET) net_forward16<S, OBS, NP, DO_P, DO_V, ETILES_>(obs, V, hs, half, ctx, out);
+        else net_forward16<S, OBS, NP, DO_P, DO_V, ETILES_>(obs, P, hs, half, ctx, out);
     }
 };
 
@@ -735,8 +739,8 @@ extern "C" {
 size_t ppo_rollout_param_floats(int kind, int joint, int net_mode)
 {
     const int obs = ppo_env_obs_dim(kind);
-    if (obs < 0 || (net_mode != PPO_NET_F32 && net_mode != PPO_NET_F16_SPLIT && net_mode != PPO_NET_BF16X3)) return 0;
-    const size_t bb = net_mode == PPO_NET_F32 ? (size_t)backbone_floats(obs) : (size_t)bb16_words(net_mode == PPO_NET_BF16X3 ? 3 : 2);
+    if (obs < 0 || net_mode < PPO_NET_F32 || net_mode > PPO_NET_BF16X3) return 0;
+    const size_t bb = net_mode == PPO_NET_F32 ? (size_t)backbone_floats(obs) : (size_t)bb16_words(net_mode == PPO_NET_F16_SPLIT ? 2 : 3);
     return bb * (joint ? 1 : 2) + (size_t)HEAD_FLOATS;
 }
 
@@ -752,7 +756,7 @@ int ppo_rollout_fused_ex(int kind, double *state, int *elapsed, float *ep_ret, i
     PPO_REQUIRE(wave_envs == 0 || wave_envs == 32 || wave_envs == 64);
     PPO_REQUIRE(kind == PPO_ENV_CARTPOLE || kind == PPO_ENV_ACROBOT);
     PPO_REQUIRE(!reward_sum || ppo_aligned(reward_sum, 8));
-    PPO_REQUIRE(net_mode == PPO_NET_F32 || net_mode == PPO_NET_F16_SPLIT || net_mode == PPO_NET_BF16X3);
+    PPO_REQUIRE(net_mode >= PPO_NET_F32 && net_mode <= PPO_NET_BF16X3);
     PPO_REQUIRE(N >= 0 && T >= 0);
     if (N == 0 || T == 0) return 0;
     PPO_REQUIRE(state && elapsed && ep_ret && ep_len && episode && params && obs_io && states && actions &&

@@ -361,7 +361,7 @@ def categorical_sample(logits: torch.Tensor, seed: int, env_base: int, step: int
 
 
 # --------------------------------------------------------------------------- fused rollout
-NET_F32, NET_F16_SPLIT, NET_BF16X3 = 0, 1, 2   # include/ppo_amd.h: PPO_NET_F32, PPO_NET_F16_SPLIT, PPO_NET_BF16X3
+NET_F32, NET_F16_SPLIT, NET_BF16X3 = 0, 1, 2   # include/ppo_amd.h: PPO_NET_*
 NET_AUTO = -1                                  # resolved here, never passed to the library
 NET_NAMES = {NET_F32: "f32", NET_F16_SPLIT: "f16_split", NET_BF16X3: "bf16x3", NET_AUTO: "auto"}
 # What NET_AUTO runs OUTSIDE the limits of the two-piece f16 split: the f32-grade three-piece bf16 kernels

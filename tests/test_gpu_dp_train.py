@@ -33,7 +33,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(out, world, kind, N, BATCH, joint=1):
+def _launch(out, world, kind, N, BATCH, joint=1, early_stop_reward=None, updates=UPDATES, extra_env=None):
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -44,7 +44,11 @@ def _launch(out, world, kind, N, BATCH, joint=1):
             env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), PPO_AMD_DIST_BACKEND="gloo")
         env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-        procs.append(subprocess.Popen([sys.executable, "-u", WORKER, out, str(N), str(T), str(BATCH), str(UPDATES), kind, str(joint)],
+        env["PPO_AMD_DP_WATCHDOG"] = "200"               # a rank that hangs dumps every thread's stack and exits
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, "-u", WORKER, out, str(N), str(T), str(BATCH), str(updates), kind, str(joint),
+                                       "none" if early_stop_reward is None else str(early_stop_reward)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -134,3 +138,31 @@ def test_world2_split_networks_with_the_fused_update(tmp_path):
     # (different samples); the parameters after it must be close: same data, same update rule, 2 x 1/2 the samples
     d = (r0["steps"][-1]["params"] - w1["steps"][-1]["params"]).abs()
     assert float(d.max()) < 0.05
+
+
+def test_world2_early_stop_reward_ends_both_ranks_together(tmp_path):
+    """reference src/ppo.py:758 leaves the training loop when max_ep_return -- over ALL envs -- reaches
+    early_stop_reward.  Under data parallelism that decision must be the same on every rank (a rank that left alone
+    would leave the others in the next update's first collective for ever): the statistics are job-wide and the
+    decision itself is a MAX all-reduce.  Few envs per rank, so that the ranks' own shards do reach the threshold
+    at different updates; PPO_AMD_DIST_DEBUG checks that both ranks enter the same collectives in the same order."""
+    N, BATCH, UPD = 16, 16 * T // 2, 40
+    r0, r1 = _launch(str(tmp_path / "es2"), 2, "cartpole", N, BATCH, early_stop_reward=60.0, updates=UPD,
+                     extra_env={"PPO_AMD_DIST_DEBUG": "1"})
+    (w1,) = _launch(str(tmp_path / "es1"), 1, "cartpole", N, BATCH, early_stop_reward=60.0, updates=UPD)
+    assert r0["updates_done"] == r1["updates_done"] < UPD               # stopped early, at the same update
+    assert r0["collectives"] == r1["collectives"] > 0                    # and after the same number of collectives
+    # job-wide statistics: both ranks log the same numbers, and at the stopping update the threshold is reached
+    for a, b in zip(r0["metrics"], r1["metrics"]):
+        for k in ("metrics/ep_return_max", "utils/ep_return_0.50", "utils/ep_return_0.05", "utils/ep_return_0.95",
+                  "metrics/ep_length_0.50"):
+            assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), (k, a[k], b[k])
+    assert r0["metrics"][-1]["metrics/ep_return_max"] >= 60.0
+    assert all(m["metrics/ep_return_max"] < 60.0 for m in r0["metrics"][:-1])
+    # the job-wide running max is the max of the ranks' own
+    for m, x, y in zip(r0["metrics"], r0["local_max"], r1["local_max"]):
+        own = [v for v in (x, y) if v == v]
+        if own:
+            assert m["metrics/ep_return_max"] == max(own)
+    # same envs, same seeds, same rollouts: the world-1 run sees the same episodes in its first rollout
+    assert w1["metrics"][0]["metrics/ep_return_max"] == r0["metrics"][0]["metrics/ep_return_max"]

@@ -206,3 +206,79 @@ def test_categorical_sample_distribution_and_logp():
     a2, _ = ops.categorical_sample(logits, seed=11, env_base=0, step=5)
     a3, _ = ops.categorical_sample(logits, seed=11, env_base=0, step=6)
     assert torch.equal(a, a2) and not torch.equal(a, a3)
+
+
+# ---- Acrobot: the termination flag at the threshold, and the RK4 stages' division --------------------------
+def _states_at_the_threshold(n, width, seed):
+    """float64 states [n, 4] whose -cos(theta1) - cos(theta1 + theta2) lies within `width` of 1.0 (both sides):
+    theta1 in the upper half plane (either sign), theta2 solved in extended precision."""
+    rng = np.random.default_rng(seed)
+    ld = np.longdouble
+    th1 = rng.uniform(np.pi / 2 + 0.05, np.pi - 0.05, n).astype(ld)
+    delta = rng.uniform(-width, width, n).astype(ld)
+    c = -ld(1) - delta - np.cos(th1)                      # cos(theta1 + theta2) that puts the lhs at 1 + delta
+    th2 = np.arccos(c) - th1
+    sign = np.where(rng.random(n) < 0.5, -1.0, 1.0)       # (theta1, theta2) -> (-theta1, -theta2): same cosines
+    st = np.empty((n, 4), dtype=np.float64)
+    st[:, 0], st[:, 1] = (sign * th1).astype(np.float64), (sign * th2).astype(np.float64)
+    st[:, 2], st[:, 3] = rng.uniform(-4 * np.pi, 4 * np.pi, n), rng.uniform(-9 * np.pi, 9 * np.pi, n)
+    return st
+
+
+@pytest.mark.parametrize("width", [1e-12, 1e-6], ids=["inside_the_guard_band", "outside_it"])
+def test_acrobot_termination_flag_is_the_reference_expressions(width):
+    """gymnasium decides termination with -cos(s0) - cos(s1 + s0) > 1.0 (AcrobotEnv._terminal; call site reference
+    src/env_acrobot.py:7).  The kernels take cos(theta1 + theta2) from the observation's sin / cos (angle-sum
+    identity) but let that value decide only outside a band of 1e-9 around the threshold; inside it they evaluate the
+    reference's expression itself.  A million states within 1e-12 of the threshold (and a million 1e-6 away): the
+    flag equals the oracle's (glibc cos) everywhere except where the left-hand side IS the threshold to within the
+    last bits -- there the device's and glibc's cos may differ by an ulp, which no formulation can remove."""
+    from ppo_amd import _lib, ops
+    lib = _lib.load()
+    n = 1 << 20
+    st = _states_at_the_threshold(n, width, seed=5)
+    want, lhs_ref = cref.acrobot_terminal(st)
+    assert np.all(np.abs(lhs_ref - 1.0) <= 1.001 * width + 1e-15)            # the construction put them there
+    assert 0.4 < want.mean() < 0.6                                            # both sides of the threshold
+    d_st = torch.from_numpy(st).cuda()
+    flag = torch.empty(n, dtype=torch.int32, device="cuda")
+    lhs = torch.empty(n, dtype=torch.float64, device="cuda")
+    _lib.check(lib.ppo_test_acrobot_terminal(d_st.data_ptr(), flag.data_ptr(), lhs.data_ptr(), n, ops._stream()),
+               "ppo_test_acrobot_terminal")
+    got, lhs = flag.cpu().numpy(), lhs.cpu().numpy()
+    assert np.abs(lhs - lhs_ref).max() < 2e-15                                # the identity's value: a few ulp from the direct one
+    differ = got != want
+    # only ON the threshold (|lhs - 1| within two ulp of 1.0) may the two libms disagree, and rarely
+    assert np.all(np.abs(lhs_ref[differ] - 1.0) <= 4.5e-16), (differ.sum(), np.abs(lhs_ref[differ] - 1.0).max())
+    assert differ.sum() <= (64 if width < 1e-9 else 0), differ.sum()
+    print(f"acrobot termination, width {width:g}: {differ.sum()} of {n} flags differ from glibc's (all with |lhs - 1| <= 2 ulp)")
+
+
+def test_acrobot_stage_division_equals_ieee_division():
+    """The four divisions of an RK4 stage (gymnasium AcrobotEnv._dsdt: d2 / d1, d2**2 / d1, the quotient that gives
+    ddtheta2, and -(...) / d1) run as Acrobot::quot -- hardware reciprocal, two Newton steps, one Markstein correction.
+    Against IEEE division (the compiler's own sequence on the device, and numpy on the host for the first chunk) on
+    2 * 10^8 operand pairs over the ranges the dynamics produce: denominators d1 = 3.5 + cos(theta2) in [2.5, 4.5]
+    and 1.25 - d2^2 / d1 in [0.57, 1.03], numerators of either sign over twelve decades."""
+    from ppo_amd import _lib, ops
+    lib = _lib.load()
+    chunk, chunks = 1 << 24, 12
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    total = bad = 0
+    for c in range(chunks):
+        u = torch.rand(chunk, dtype=torch.float64, device="cuda", generator=gen)
+        den = torch.where(torch.rand(chunk, device="cuda", generator=gen) < 0.5, 2.5 + 2.0 * u, 0.57 + 0.46 * u)
+        mag = 10.0 ** (torch.rand(chunk, dtype=torch.float64, device="cuda", generator=gen) * 12.0 - 8.0)
+        num = torch.where(torch.rand(chunk, device="cuda", generator=gen) < 0.5, -mag, mag)
+        if c == 0:                                          # the operands the dynamics divide most often
+            num[: chunk // 4] = 1.25 + 0.5 * torch.cos(u[: chunk // 4] * 6.283185307179586)     # d2
+            num[chunk // 4: chunk // 2] = num[: chunk // 4] ** 2                                    # d2^2
+        qf, qi = torch.empty_like(num), torch.empty_like(num)
+        _lib.check(lib.ppo_test_acrobot_quot(num.data_ptr(), den.data_ptr(), qf.data_ptr(), qi.data_ptr(), chunk, ops._stream()),
+                   "ppo_test_acrobot_quot")
+        bad += int((qf.view(torch.int64) != qi.view(torch.int64)).sum())
+        total += chunk
+        if c == 0:
+            host = num.cpu().numpy() / den.cpu().numpy()
+            assert np.array_equal(host.view(np.int64), qi.cpu().numpy().view(np.int64))     # the device's `/` is IEEE
+    assert total >= 2 * 10 ** 8 and bad == 0, (bad, total)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Build variants/lib<name>.so: the shipped objects with rollout.hip recompiled under extra flags (development A/B aid).
+# usage: tools/build_variant.sh <name> [-DFLAG=..] ...
+set -e
+name=$1; shift
+cd "$(dirname "$0")/../ppo_amd/csrc"
+mkdir -p ../../variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
+    -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c rollout.hip -o ../../variants/rollout_$name.o
+objs=$(ls *.o | grep -v '^rollout.o$')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib$name.so $objs ../../variants/rollout_$name.o
+echo "built variants/lib$name.so"

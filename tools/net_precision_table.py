@@ -15,7 +15,7 @@ import test_gpu_net_precision as T
 from ppo_amd import Agent, ops
 from ppo_amd.envs import DeviceEnv
 
-print("kind joint scale head | floor margin, rms row norm W1', W2' | split: v lp | bf16x3: v lp | f32 mfma: v lp | torch f32: v lp   (max abs error over 2^18 states) | rms v: bf16x3 f32mfma torch")
+print("kind joint scale head | floor margin, rms row norm W1', W2' | split: v lp | bf16x3: v lp | f32 mfma: v lp | torch f32: v lp   (max abs error over 2^18 states) | rms v: split bf16x3 f32mfma torch")
 for kind in ("cartpole", "acrobot"):
     gen = torch.Generator(device="cuda").manual_seed(11)
     states = T._states(kind, T.NSTATES, gen)
@@ -40,8 +40,7 @@ for kind in ("cartpole", "acrobot"):
                     v, act, lp, _ = T._kernel_forward(kind, agent, states, mode)
                     v64, lp64 = T._f64(agent, states, act)
                     out += [float((v.double() - v64).abs().max()), float((lp.double() - lp64).abs().max())]
-                    if mode != ops.NET_F16_SPLIT:
-                        rms.append(float((v.double() - v64).pow(2).mean().sqrt()))
+                    rms.append(float((v.double() - v64).pow(2).mean().sqrt()))
                 act = torch.zeros(T.NSTATES, dtype=torch.int32, device="cuda")
                 v64, lp64 = T._f64(agent, states, act)
                 vt, lpt = T._f32_torch(agent, states, act)
