@@ -382,6 +382,26 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
                                   void *stream);
 
 /*
+ * Job-wide episode statistics when the envs are sharded over data-parallel ranks.  The reference takes its
+ * percentiles over EVERY env's deques (src/ppo.py:404-417); with one env shard per GPU the same numbers come from
+ * a radix select whose histograms are added up over the ranks, one all-reduce per level, and narrowed by the
+ * caller (ppo_amd/ppo.py: SyncVecEnv.job_wide_episode_stats).  Keys: k(x) = bits(x) ^ 0xffffffff for negative
+ * floats, bits(x) | 0x80000000 otherwise (unsigned order = float order); lengths are counted as (float)length.
+ *   - level 0: ppo_episode_stats_incremental keeps it.  At byte offset ppo_episode_stats_hist0_offset() of its
+ *     state block: u32 [2][4096], counts of k >> 20 over the valid ring entries, returns then lengths.
+ *   - levels 1 and 2: ppo_episode_hist_level ADDS to hist (device u32 [9 * 1024 + 1], zeroed by the caller) the
+ *     counts of (k >> 10) & 1023 (level 1) or k & 1023 (level 2) over the valid ring entries whose higher key
+ *     bits, k >> 20 (level 1) or k >> 10 (level 2), equal a listed prefix: row q < n_ret (<= 7) for returns
+ *     under prefixes[q], row 7 + q, q < n_len (<= 2), for lengths under prefixes[7 + q]; prefixes: device u32[9].
+ *     Level 1 also adds to hist[9 * 1024] a non-zero count if a matched value has any of its low 10 float bits set
+ *     (zero on every rank: the 22 bits known after level 1 are the whole key -- integer-valued statistics).
+ */
+size_t ppo_episode_stats_hist0_offset(void);
+int ppo_episode_hist_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
+                           int level, const uint32_t *prefixes, int n_ret, int n_len, uint32_t *hist,
+                           void *stream);
+
+/*
  * One minibatch of the update for the dense Agent with a Discrete head, fused: forward, loss,
  * backward and weight gradients in one pass over the samples.  Replaces, for one backbone and the
  * head(s) on it, Agent.get_actions_and_values on the minibatch (src/ppo.py:166-216, network

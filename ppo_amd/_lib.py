@@ -45,6 +45,8 @@ SIGNATURES = {
     "ppo_episode_stats": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ppo_episode_stats_state_bytes": (_sz, [_i, _i]),
     "ppo_episode_stats_incremental": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "ppo_episode_stats_hist0_offset": (_sz, []),
+    "ppo_episode_hist_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ppo_rollout_param_floats": (_sz, [_i, _i, _i]),
     "ppo_rollout_pack_params": (_i, [_i, _i, _i] + [_vp] * 14 + [_vp]),
     "ppo_rollout_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp,

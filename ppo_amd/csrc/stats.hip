@@ -324,31 +324,19 @@ template <int LEVEL, bool INCR> __device__ void sel_narrow(const SelWs &w, const
     else sel_finalize(stats5, s_prefix, LEVEL == 1 ? 22 : 32, n);
 }
 
-template <int LEVEL, bool INCR>
-__global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, const int *len_ring, const int *ring_cnt,
-                                                      int ring, int N, SelWs w, double *stats5)
+// Histogram pass of one level over the rings into the workgroup's LDS histogram(s) h (zeroed by the caller):
+// level 0 counts the top 12 key bits of every valid entry (returns into h[0 .. SEL_B0), lengths behind them);
+// levels 1 / 2 count the next 10 bits of the entries whose higher key bits equal one of the listed prefixes
+// (returns: lprefix[0 .. nlead_ret), lengths: lprefix[SEL_T_RET .. SEL_T_RET + nlead - nlead_ret)) into row lslot[q].
+// `low` collects the low 10 float bits of every matched value (level 1).
+template <int LEVEL>
+__device__ __forceinline__ void sel_walk(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
+                                         uint32_t *h, const uint32_t (&lprefix)[SEL_T], const int (&lslot)[SEL_T],
+                                         int nlead_ret, int nlead, uint32_t &low)
 {
-    constexpr int NH = LEVEL == 0 ? 2 : SEL_T, NB = LEVEL == 0 ? SEL_B0 : SEL_B1;
+    constexpr int NB = LEVEL == 0 ? SEL_B0 : SEL_B1;
     constexpr int SHIFT = LEVEL == 0 ? 20 : (LEVEL == 1 ? 10 : 0);     // digit position
     constexpr int PSHIFT = LEVEL == 1 ? 20 : 10;                       // bits below the fixed prefix
-    __shared__ uint32_t h[LEVEL == 0 ? SEL_H0_LDS : NH * NB];   // level 0: room for the padded copy the narrowing reads
-    __shared__ int s_is_last;
-    uint32_t lprefix[SEL_T];
-    int lslot[SEL_T], nlead_ret = 0, nlead = 0;
-    if (LEVEL > 0) {
-        if (w.st->n == 0) return;                                      // uniform: nothing finished yet
-        if (INCR && LEVEL == 1 && w.st->skip1) return;                 // uniform: every wanted prefix is tracked
-        if (LEVEL == 2 && w.st->skip2) return;                         // uniform: level 1 finished the selection
-        nlead_ret = __builtin_amdgcn_readfirstlane(w.st->nlead_ret);
-        nlead = __builtin_amdgcn_readfirstlane(w.st->nlead);
-#pragma unroll
-        for (int q = 0; q < SEL_T; ++q) {
-            lprefix[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.st->lprefix[q]);
-            lslot[q] = __builtin_amdgcn_readfirstlane(w.st->lslot[q]);
-        }
-    }
-    for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK) h[k] = 0u;
-    __syncthreads();
     // Flat walk over the N * ring slots: a wave takes 64 SEL_U consecutive slots at a time, lane l
     // the slots l, l + 64, ...; the (ring, index in ring) pair of the first one costs one division,
     // the others follow by adding 64 = q64 ring + r64.  A slot is valid if its index in the ring is
@@ -360,7 +348,6 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, co
     const uint32_t q64 = 64u / uring, r64 = 64u - q64 * uring;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = blockIdx.x * (SEL_HBLOCK / 64) + (threadIdx.x >> 6), nwv = gridDim.x * (SEL_HBLOCK / 64);
-    uint32_t low = 0u;                                                 // level 1: low 10 bits of the keys that matched
     for (uint32_t b = wv * (64u * SEL_U); b < total; b += nwv * (64u * SEL_U)) {
         const uint32_t i0 = b + lane;
         uint32_t n = i0 / uring, k = i0 - n * uring;
@@ -415,6 +402,34 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, co
             }
         }
     }
+}
+
+template <int LEVEL, bool INCR>
+__global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, const int *len_ring, const int *ring_cnt,
+                                                      int ring, int N, SelWs w, double *stats5)
+{
+    constexpr int NH = LEVEL == 0 ? 2 : SEL_T, NB = LEVEL == 0 ? SEL_B0 : SEL_B1;
+    __shared__ uint32_t h[LEVEL == 0 ? SEL_H0_LDS : NH * NB];   // level 0: room for the padded copy the narrowing reads
+    __shared__ int s_is_last;
+    uint32_t lprefix[SEL_T];
+    int lslot[SEL_T], nlead_ret = 0, nlead = 0;
+    if (LEVEL > 0) {
+        if (w.st->n == 0) return;                                      // uniform: nothing finished yet
+        if (INCR && LEVEL == 1 && w.st->skip1) return;                 // uniform: every wanted prefix is tracked
+        if (LEVEL == 2 && w.st->skip2) return;                         // uniform: level 1 finished the selection
+        nlead_ret = __builtin_amdgcn_readfirstlane(w.st->nlead_ret);
+        nlead = __builtin_amdgcn_readfirstlane(w.st->nlead);
+#pragma unroll
+        for (int q = 0; q < SEL_T; ++q) {
+            lprefix[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.st->lprefix[q]);
+            lslot[q] = __builtin_amdgcn_readfirstlane(w.st->lslot[q]);
+        }
+    }
+    for (int k = threadIdx.x; k < NH * NB; k += SEL_HBLOCK) h[k] = 0u;
+    __syncthreads();
+    uint32_t low = 0u;                                                 // level 1: low 10 bits of the keys that matched
+    sel_walk<LEVEL>(ret_ring, len_ring, ring_cnt, ring, N, h, lprefix, lslot, nlead_ret, nlead, low);
+    const uint32_t lane = threadIdx.x & 63u;
     if (LEVEL == 1 && !INCR) {
         if (__any(low != 0u) && lane == 0) atomicOr(&w.st->low_bits, 1u);   // device-scope atomic, like the histogram adds
     }
@@ -443,6 +458,35 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, co
     f.template store<LEVEL == 0>(h);
     __syncthreads();
     sel_narrow<LEVEL, INCR>(w, h, stats5);
+}
+
+// Histogram pass alone, for a selection that is narrowed OUTSIDE this library: data-parallel ranks add up their
+// histograms (one all-reduce per level) and narrow the job-wide ranks on the host (ppo_amd/ppo.py,
+// SyncVecEnv.job_wide_episode_stats).  Row q < n_ret counts returns under prefixes[q], row SEL_T_RET + q < SEL_T_RET +
+// n_len lengths under prefixes[SEL_T_RET + q]; word SEL_T * SEL_B1 counts matched values with low float bits set.
+template <int LEVEL>
+__global__ void __launch_bounds__(SEL_HBLOCK, 2) k_hist_level(const float *ret_ring, const int *len_ring, const int *ring_cnt,
+                                                             int ring, int N, const uint32_t *prefixes, int n_ret, int n_len,
+                                                             uint32_t *hist)
+{
+    __shared__ uint32_t h[SEL_T * SEL_B1];
+    uint32_t lprefix[SEL_T];
+    int lslot[SEL_T];
+#pragma unroll
+    for (int q = 0; q < SEL_T; ++q) {
+        lprefix[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)prefixes[q]);
+        lslot[q] = q;
+    }
+    for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_HBLOCK) h[k] = 0u;
+    __syncthreads();
+    uint32_t low = 0u;
+    sel_walk<LEVEL>(ret_ring, len_ring, ring_cnt, ring, N, h, lprefix, lslot, n_ret, n_ret + n_len, low);
+    if (LEVEL == 1 && __any(low != 0u) && (threadIdx.x & 63) == 0) atomicAdd(&hist[SEL_T * SEL_B1], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < SEL_T * SEL_B1; k += SEL_HBLOCK) {
+        const uint32_t v = h[k];
+        if (v) atomicAdd(&hist[k], v);
+    }
 }
 
 template <int LEVEL, bool INCR = false>
@@ -713,6 +757,29 @@ int ppo_episode_stats(const float *ret_ring, const int *len_ring, const int *rin
     rc = sel_level<1>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
     if (rc) return rc;
     return sel_level<2>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
+}
+
+size_t ppo_episode_stats_hist0_offset(void) { return SEL_STATE_BYTES; }
+
+int ppo_episode_hist_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N, int level,
+                           const uint32_t *prefixes, int n_ret, int n_len, uint32_t *hist, void *stream)
+{
+    PPO_REQUIRE(N >= 0 && ring > 0 && (unsigned long long)N * (unsigned long long)ring < 0xFFFFFFFFull);
+    PPO_REQUIRE((level == 1 || level == 2) && prefixes && hist && ppo_aligned(prefixes, 4) && ppo_aligned(hist, 4));
+    PPO_REQUIRE(n_ret >= 0 && n_ret <= SEL_T_RET && n_len >= 0 && n_len <= SEL_T - SEL_T_RET);
+    if (N == 0) return 0;
+    PPO_REQUIRE(ret_ring && len_ring && ring_cnt);
+    size_t blocks = ((size_t)N * ring + SEL_HBLOCK * SEL_U - 1) / (SEL_HBLOCK * SEL_U);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (level == 1)
+        PPO_LAUNCH(k_hist_level<1>, dim3((unsigned)blocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, prefixes,
+                   n_ret, n_len, hist);
+    else
+        PPO_LAUNCH(k_hist_level<2>, dim3((unsigned)blocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, prefixes,
+                   n_ret, n_len, hist);
+    return ppo_launch_status();
 }
 
 size_t ppo_episode_stats_state_bytes(int N, int ring)

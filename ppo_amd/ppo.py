@@ -194,6 +194,7 @@ class SyncVecEnv:
         self._stats_state = None
         self._rsum_pool, self._rsum_next = torch.empty(0), 0
         self._total_return = np.float32(0.0)
+        self._local_max = np.float32(np.nan)       # host-stepped envs under data parallelism: this rank's own running max
         self._end_states = None
         self.state_space, self.action_space = agent.state_space, agent.action_space
         self.action_dtype = torch.int32 if spaces.is_discrete(self.action_space) else torch.float32
@@ -488,8 +489,11 @@ class SyncVecEnv:
 
     def _stat(self, key):
         self._flush_stats()
-        if self._stats_dev is not None:                 # one device->host copy for all five values
-            self._note_stats(self._stats_dev.cpu().numpy())
+        if self._stats_dev is not None:
+            if ppo_dist.is_dist():                      # this rank's shard only: the logged statistics are job-wide,
+                self._stats_dev = None                  # made by job_wide_episode_stats (every rank, once per update)
+            else:                                       # one device->host copy for all five values
+                self._note_stats(self._stats_dev.cpu().numpy())
         return self._stats_host[key]
 
     def _note_stats(self, v):
@@ -522,7 +526,92 @@ class SyncVecEnv:
     @property
     def local_max_ep_return(self):
         """Running max over THIS rank's envs only (max_ep_return is job-wide under data parallelism)."""
-        return self._stat("max")
+        if not ppo_dist.is_dist() or not self.native:
+            return self._local_max if (ppo_dist.is_dist() and not self.native) else self._stat("max")
+        self._flush_stats()
+        return np.float32(self._stats5[0].item()) if self._stats5 is not None else np.float32(np.nan)
+
+    # -- job-wide statistics under data parallelism -------------------------------------------------
+    def job_wide_episode_stats(self) -> float:
+        """Data parallel: the reference's statistics tail (src/ppo.py:404-417) over the deques of ALL envs of the
+        job, not of this rank's shard -- running max, 5/50/95 percentiles of the returns, median length -- and the
+        job's reward sum of the last rollout (:318, :348), which it returns.  EVERY rank must call it, once per
+        update (collectives: one gather of two floats per rank, then one histogram sum per level of the radix
+        select -- 32 KB and 36 KB -- narrowed identically on every rank's host).  Exact: the same nine order
+        statistics ppo_episode_stats selects, np.percentile's "linear" interpolation."""
+        if not self.native:
+            return self._job_wide_host_stats()
+        lib = ops._lib.load()
+        b = self.batch
+        self._flush_stats()
+        dev = b.device
+        tr = self._total_return
+        tr = tr.detach().to(torch.float64).reshape(1) if isinstance(tr, torch.Tensor) else torch.tensor([float(tr)], dtype=torch.float64)
+        own_max = self._stats5[0:1] if self._stats5 is not None else torch.full((1,), float("nan"), dtype=torch.float64, device=dev)
+        pair = torch.cat([torch.nan_to_num(own_max, nan=-float("inf")).to(dev), tr.to(dev)])
+        rows = ppo_dist.gather_rows(pair, "ep_max_and_reward_sum").cpu().numpy()
+        job_max, job_reward = float(rows[:, 0].max()), float(rows[:, 1].sum())
+        self._stats_dev = None
+        if self._stats_state is None:                      # no rollout yet
+            return job_reward
+        off = lib.ppo_episode_stats_hist0_offset()
+        h0 = self._stats_state[off:off + 2 * 4096 * 4].view(torch.int32).clone()
+        h0 = ppo_dist.sum_tensor(h0, "ep_hist0").cpu().numpy().view(np.uint32).reshape(2, 4096).astype(np.int64)
+        n = int(h0[0].sum())
+        if n == 0:                                         # no episode has finished anywhere yet
+            return job_reward
+        ranks = _select_ranks(n)
+        c0 = [np.cumsum(h0[0]), np.cumsum(h0[1])]
+        pref, resid = [], []
+        for t, r in enumerate(ranks):
+            bkt, rem = _bucket_of(c0[0 if t < 7 else 1], r)
+            pref.append(bkt)
+            resid.append(rem)
+        for level in (1, 2):
+            lists = [sorted(set(pref[:7])), sorted(set(pref[7:]))]
+            table = np.full(9, 0xFFFFFFFF, dtype=np.uint32)
+            table[:len(lists[0])] = lists[0]
+            table[7:7 + len(lists[1])] = lists[1]
+            d_table = torch.from_numpy(table.view(np.int32)).to(dev)
+            hist = torch.zeros(9 * 1024 + 1, dtype=torch.int32, device=dev)
+            ops._lib.check(lib.ppo_episode_hist_level(b.ret_ring.data_ptr(), b.len_ring.data_ptr(), b.ring_cnt.data_ptr(),
+                                                      b.ring, b.num_envs, level, d_table.data_ptr(), len(lists[0]),
+                                                      len(lists[1]), hist.data_ptr(), ops._stream()),
+                           "ppo_episode_hist_level")
+            hist = ppo_dist.sum_tensor(hist, f"ep_hist{level}").cpu().numpy().view(np.uint32).astype(np.int64)
+            rowsum = np.cumsum(hist[:9 * 1024].reshape(9, 1024), axis=1)
+            for t in range(9):
+                row = lists[0].index(pref[t]) if t < 7 else 7 + lists[1].index(pref[t])
+                bkt, resid[t] = _bucket_of(rowsum[row], resid[t])
+                pref[t] = (pref[t] << 10) | bkt
+            if level == 1 and hist[9 * 1024] == 0:         # integer-valued statistics: 22 key bits are the whole key
+                pref = [(p << 10) | (0 if (p >> 21) & 1 else 1023) for p in pref]
+                break
+        v = _key_to_float(np.array(pref, dtype=np.uint64))
+        self._note_stats([job_max if job_max > -float("inf") else v[6], _lerp(v[0], v[1], n, 0.05), _lerp(v[2], v[3], n, 0.50),
+                          _lerp(v[4], v[5], n, 0.95), _lerp(v[7], v[8], n, 0.50)])
+        if not (self._stats_host["max"] >= v[6]):
+            self._stats_host["max"] = np.float32(v[6])
+        return job_reward
+
+    def _job_wide_host_stats(self) -> float:
+        """job_wide_episode_stats for host-stepped envs (BASELINE configs[4]: Ant sharded over the node): every rank's
+        deques in one padded gather, then the reference's own percentiles over all of them."""
+        N = self.num_envs
+        cap = N * 100
+        has = self.envs is not None and hasattr(self.envs[0], "return_queue")
+        rets = np.concatenate([np.array(e.return_queue, dtype=np.float64).reshape(-1) for e in self.envs]) if has else np.zeros(0)
+        lens = np.concatenate([np.array(e.length_queue, dtype=np.float64).reshape(-1) for e in self.envs]) if has else np.zeros(0)
+        mine = np.zeros(3 + 2 * cap, dtype=np.float64)
+        mine[0], mine[1], mine[2] = float(self.total_return), rets.size, lens.size
+        mine[3:3 + rets.size] = rets
+        mine[3 + cap:3 + cap + lens.size] = lens
+        rows = ppo_dist.gather_rows(torch.from_numpy(mine), "ep_deques_host").numpy()
+        all_r = np.concatenate([r[3:3 + int(r[1])] for r in rows])
+        all_l = np.concatenate([r[3 + cap:3 + cap + int(r[2])] for r in rows])
+        self._local_max = np.float32(rets.max()) if rets.size else getattr(self, "_local_max", np.float32(np.nan))
+        self._episode_percentiles(torch.from_numpy(all_r), torch.from_numpy(all_l))
+        return float(rows[:, 0].sum())
 
     max_ep_return = property(lambda self: self._stat("max"),
                              lambda self, v: self._stats_host.__setitem__("max", v))
@@ -628,6 +717,35 @@ class SyncVecEnv:
         if lens.numel() > 0:
             srt = torch.sort(lens.to(torch.float64)).values
             self.median_ep_length = np.float64(_percentiles(srt, (50.0,)).item())
+
+
+def _select_ranks(n: int):
+    """Ranks (0-based, among n values) of the nine order statistics behind the reference's statistics: lower / upper
+    neighbour of the 5th, 50th and 95th percentile of the returns (np.percentile, method "linear"), their maximum,
+    lower / upper neighbour of the median length -- csrc/stats.hip sel_target_rank."""
+    def pair(q):
+        lo = int(np.floor(q * float(n - 1)))
+        return lo, min(lo + 1, n - 1)
+    p5, p50, p95 = pair(0.05), pair(0.50), pair(0.95)
+    return [p5[0], p5[1], p50[0], p50[1], p95[0], p95[1], n - 1, p50[0], p50[1]]
+
+
+def _bucket_of(cum: np.ndarray, rank: int):
+    """(bucket holding the entry of 0-based rank `rank`, its rank inside that bucket) from inclusive counts."""
+    bkt = int(np.searchsorted(cum, rank, side="right"))
+    return bkt, rank - (int(cum[bkt - 1]) if bkt > 0 else 0)
+
+
+def _key_to_float(keys: np.ndarray) -> np.ndarray:
+    """Inverse of the order-preserving f32 -> u32 map of csrc/stats.hip (f2key), as float64 values."""
+    k = keys.astype(np.uint32)
+    bits = np.where(k & np.uint32(0x80000000), k & np.uint32(0x7FFFFFFF), ~k)
+    return bits.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+def _lerp(a: float, b: float, n: int, q: float) -> float:
+    pos = q * float(n - 1)
+    return float(a + (b - a) * (pos - np.floor(pos)))
 
 
 def _percentiles(sorted_vals: torch.Tensor, qs) -> torch.Tensor:
@@ -875,6 +993,7 @@ class PPO:
         n_own = 6 if rows_form else 5
         if diag is not None:
             pieces.append(diag.to(dev))
+        job_reward = ve.job_wide_episode_stats() if world > 1 else None      # every rank, once per update (collectives)
         ve_vals, ve_take = ve.pending_device_scalars() if (ve.native and dev.type == "cuda") else (None, None)
         if ve_vals is not None and ve_vals.device == dev:
             pieces.append(ve_vals)                             # f64: torch.cat promotes the f32 pieces exactly
@@ -895,7 +1014,7 @@ class PPO:
 
         policy_loss, critic_loss, entropy, kl_div = host[0], host[1], host[2], host[3]
         clip_frac = float(host[4] / max(grad_steps_done, 1))
-        rollout_return = float(ve.total_return) / num_envs
+        rollout_return = float(ve.total_return) / num_envs if world == 1 else job_reward / (num_envs * world)   # :318, :348 over all envs
         ep_return_max = float(ve.max_ep_return)
         self.last_metrics = {  # reference :656-670, same names
             "utils/ep_return_0.50": float(ve.median_ep_return),

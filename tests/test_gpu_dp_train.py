@@ -118,6 +118,19 @@ def test_world2_training_equals_the_single_process_run(tmp_path, kind, N, BATCH)
     # the job-level rate uses the slowest rank's time: both ranks report the same figure
     for a, b in zip(r0["metrics"], r1["metrics"]):
         assert a["utils/env_steps_per_sec"] == b["utils/env_steps_per_sec"] > 0
+    # episode statistics and the rollout's mean reward are JOB-WIDE (reference src/ppo.py:404-417, :318 over all
+    # envs): identical on both ranks in every update, and in update 0 -- the same rollout bit for bit -- equal to the
+    # single-process run's
+    same = lambda x, y: x == y or (x != x and y != y)
+    stat_keys = ("metrics/ep_return_max", "utils/ep_return_0.05", "utils/ep_return_0.50", "utils/ep_return_0.95",
+                 "metrics/ep_length_0.50", "metrics/roll_return")
+    for a, b in zip(r0["metrics"], r1["metrics"]):
+        for k in stat_keys:
+            assert same(a[k], b[k]), (k, a[k], b[k])
+    for k in stat_keys:
+        assert same(r0["metrics"][0][k], w1["metrics"][0][k]), (k, r0["metrics"][0][k], w1["metrics"][0][k])
+    if kind == "cartpole":                                      # (no Acrobot episode ends within 3 x 32 steps)
+        assert r0["metrics"][0]["utils/ep_return_0.50"] == r0["metrics"][0]["utils/ep_return_0.50"]   # not NaN
 
 
 def test_world2_split_networks_with_the_fused_update(tmp_path):

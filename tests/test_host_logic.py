@@ -173,3 +173,60 @@ def test_clip_adam_supported_is_host_logic():
     assert not ops.clip_adam_supported(torch.optim.Adam([{"params": [w]}, {"params": [torch.nn.Parameter(torch.zeros(2))]}]))
     assert not ops.clip_adam_supported(torch.optim.AdamW([w]))
     assert not ops.clip_adam_supported(torch.optim.SGD([w], lr=0.1))
+
+
+# ---- job-wide episode statistics: the host-side narrowing of the distributed radix select -------------------
+def _f2key(x32):
+    """numpy restatement of csrc/stats.hip f2key (order-preserving f32 -> u32)."""
+    u = np.asarray(x32, dtype=np.float32).view(np.uint32)
+    return np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def _select_like_the_ranks_do(returns, lengths):
+    """The selection SyncVecEnv.job_wide_episode_stats runs, with the (all-reduced) histograms made here in numpy:
+    level 0 = 12 key bits, levels 1 / 2 = 10 bits each under the prefixes still in play."""
+    from ppo_amd.ppo import _bucket_of, _key_to_float, _lerp, _select_ranks
+    kr, kl = _f2key(returns), _f2key(np.asarray(lengths, dtype=np.float32))
+    n = kr.size
+    ranks = _select_ranks(n)
+    h0 = [np.bincount(kr >> 20, minlength=4096), np.bincount(kl >> 20, minlength=4096)]
+    pref, resid = [], []
+    for t, r in enumerate(ranks):
+        b, rem = _bucket_of(np.cumsum(h0[0 if t < 7 else 1]), r)
+        pref.append(b); resid.append(rem)
+    for level in (1, 2):
+        shift, pshift = (10, 20) if level == 1 else (0, 10)
+        low = 0
+        for t in range(9):
+            k = kr if t < 7 else kl
+            m = (k >> pshift) == pref[t]
+            if level == 1:
+                vals = (returns if t < 7 else np.asarray(lengths, dtype=np.float32))[m]
+                low |= int((np.asarray(vals, dtype=np.float32).view(np.uint32) & 1023).any())
+            hist = np.bincount((k[m] >> shift) & 1023, minlength=1024)
+            b, resid[t] = _bucket_of(np.cumsum(hist), resid[t])
+            pref[t] = (pref[t] << 10) | b
+        if level == 1 and not low:
+            pref = [(p << 10) | (0 if (p >> 21) & 1 else 1023) for p in pref]
+            break
+    v = _key_to_float(np.array(pref, dtype=np.uint64))
+    return [v[6], _lerp(v[0], v[1], n, 0.05), _lerp(v[2], v[3], n, 0.50), _lerp(v[4], v[5], n, 0.95), _lerp(v[7], v[8], n, 0.50)]
+
+
+@pytest.mark.parametrize("kind", ["integers", "negative_integers", "floats", "one", "two", "duplicates"])
+def test_job_wide_selection_equals_numpy_percentile(kind):
+    """reference src/ppo.py:407-417: np.max, np.percentile([5, 50, 95]) of all returns, np.percentile(50) of all lengths."""
+    rng = np.random.default_rng(3)
+    n = {"one": 1, "two": 2}.get(kind, 5000)
+    if kind == "integers":
+        rets = rng.integers(8, 500, n).astype(np.float32)
+    elif kind == "negative_integers":
+        rets = -rng.integers(60, 500, n).astype(np.float32)
+    elif kind == "duplicates":
+        rets = np.full(n, 500.0, dtype=np.float32); rets[:7] = 499.0
+    else:
+        rets = (rng.standard_normal(n) * 300).astype(np.float32)
+    lens = rng.integers(1, 500, n).astype(np.int32)
+    got = _select_like_the_ranks_do(rets, lens)
+    want = [rets.max(), *np.percentile(rets.astype(np.float64), [5, 50, 95]), np.percentile(lens.astype(np.float64), 50)]
+    assert np.array_equal(np.array(got, dtype=np.float64), np.array(want, dtype=np.float64)), (got, want)
