@@ -53,8 +53,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense BF16/FP16 MFMA
-GAE_BYTES_PER_ELEM = 20        # r, v, done, trunc read + adv written; the end value is read only where
-                               # trunc != 0 (4 B more for those cells).  SURVEY.md 8d's dense count is 24.
+GAE_BYTES_PER_ELEM = 12.25     # the trainer's GAE (ppo_gae_dense_packed): r, v and two flag BITS read, adv written; the
+                               # end value is read only where trunc != 0 (4 B more for those cells).  The API form
+                               # (ppo_gae_dense, two i32 flag arrays) moves 20; SURVEY.md 8d's dense count is 24.
 
 
 def parse():
@@ -255,8 +256,11 @@ def main():
             # hipExtLaunchKernelGGL start/stop events on the GAE dispatch itself (ppo_gae_dense_timed in
             # csrc/gae.hip); read back after the timed region.  Agrees with rocprofv3 --kernel-trace.
             slot = len(gae_events) if record else None
-            adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95,
-                                prof_slot=slot)
+            if ve._ev_ready:                       # ... and the packed flag bits: the trainer's path (PPO._rollout_advantages)
+                adv = ops.gae_dense_packed(ve.rewards, ve.values, ev_dense, ve._flag_words, 0.99, 0.95, prof_slot=slot)
+            else:
+                adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95,
+                                    prof_slot=slot)
             if record:
                 gae_events.append(slot)
         return adv
@@ -349,18 +353,23 @@ def main():
     for _ in range(4):
         hot_path_step(False)
     per_kernel = []
+    bd_t0 = 0.0
     for k in range(16):
+        if k == 4:                                 # (first four: settle)
+            torch.cuda.synchronize()
+            bd_t0 = time.perf_counter()
         _lib.check(lib.ppo_prof_arm(128 + 5 * k, 5), "ppo_prof_arm")
         hot_path_step(False)
     _lib.check(lib.ppo_prof_arm(0, 0), "ppo_prof_arm")
     torch.cuda.synchronize()
+    bd_wall_us = (time.perf_counter() - bd_t0) / 12 * 1e6     # wall time per step of the same twelve (instrumented) steps
     per_kernel = np.array([[slot_us(128 + 5 * k + j) for j in range(5)] for k in range(4, 16)])   # (first four: settle)
     stats_us, ro_us, gae_bd_us = per_kernel[:, :3].sum(1).mean(), per_kernel[:, 3].mean(), per_kernel[:, 4].mean()
     ro_ms = float(ro_us) * 1e-3
     waves = (N + 63) // 64 if N > 32768 else (N + 31) // 32          # 64- or 32-env waves (csrc/rollout.hip)
     mfma_per_wave_step = 60 if N > 32768 else 30                      # 32x32x16 f16 MFMAs, joint net
     ro_flops = mfma_per_wave_step * 2 * 32 * 32 * 16 * waves * T
-    ro_bytes = (4 * probe.observation_space.shape[0] + 24) * N * T    # states + action, log-prob, value, reward, 2 flags
+    ro_bytes = (4 * probe.observation_space.shape[0] + 24.25) * N * T # states + action, log-prob, value, reward, 2 flags, flag bits
 
     gae_us = [slot_us(slot) for slot in gae_events]
     gae_ms = float(np.mean(gae_us)) * 1e-3 if gae_us else float("nan")
@@ -368,7 +377,7 @@ def main():
     gae_bytes = int(GAE_BYTES_PER_ELEM * T * N + 4 * n_trunc)
     achieved = gae_bytes / (gae_ms * 1e-3) / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "gae_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_gae_packed_pmc_traffic.json")
     if os.path.exists(pmc):  # per-launch HBM bytes from rocprofv3 --pmc passes at this shape
         rec = json.load(open(pmc))
         if rec.get("T") == T and rec.get("N") == N:
@@ -399,21 +408,27 @@ def main():
             "config": {"workload": f"{kind} batched stepping + GAE, N={N} envs/GPU x T={T}, dense 64-64 tanh policy "
                                    f"(joint net, f32) inside the whole-rollout kernel, BASELINE configs[1]",
                        "num_envs_per_gpu": N, "rollout_len": T, "net_mode": f"auto -> {mode_used}", "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"kernel": "k_gae (ppo_gae_dense)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_gae_words (ppo_gae_dense_packed)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes,
+                         "achieved_at_api_20B_per_elem": 20 * T * N / (gae_ms * 1e-3) / 1e9,
                          "achieved_if_dense_24B_per_elem": 24 * T * N / (gae_ms * 1e-3) / 1e9,
-                         "note": "algorithmic bytes = 20 B/element (r, v, done, trunc in; adv out) + 4 B per "
-                                 "truncated cell; SURVEY.md 8d's dense convention (24 B/element) is given beside it. "
-                                 "Timed inside the pipeline: part of the input, written by the rollout kernel just "
-                                 "before, is served by the 256 MiB Infinity Cache; with cold inputs (tools/tune_gae.py, "
-                                 "4 rotating buffer sets) the same kernel takes 35.8 us = 58.7 % of peak, and `traffic` "
-                                 "is the L2-to-fabric byte count of that cold run"},
+                         "note": "algorithmic bytes = what this kernel has to move: 12.25 B/element (r, v, two flag bits "
+                                 "in; adv out) + 4 B per truncated cell.  The same scan through the API's two i32 flag "
+                                 "arrays (ppo_gae_dense) is 20 B/element and SURVEY.md 8d's dense convention 24: the two "
+                                 "achieved_* fields price this launch's duration at those counts (work done per second "
+                                 "in the reference's terms, not bytes moved).  Timed inside the pipeline: part of the "
+                                 "input, written by the rollout kernel just before, is served by the 256 MiB Infinity "
+                                 "Cache; with HBM-cold inputs (profiles/r03_gae_packed_variants.txt) the kernel takes "
+                                 "23.6 us, and `traffic` is the L2-to-fabric byte count of such a cold launch"},
             "step_breakdown_us": {"episode_statistics_3_kernels": float(stats_us), "k_rollout": float(ro_us),
                                   "k_gae": float(gae_bd_us), "sum": float(stats_us + ro_us + gae_bd_us),
+                                  "wall_per_step_of_these_steps": float(bd_wall_us),
                                   "note": "kernel durations from dispatch timestamps (ppo_prof_arm), means over 12 "
-                                          "back-to-back steps after the timed region; ms_per_step minus the sum is "
-                                          "dispatch gaps between the five launches of a step"},
+                                          "back-to-back steps after the timed region, with the wall time per step of those "
+                                          "same twelve steps (every launch carrying an event pair, ~1 us each, so they run "
+                                          "a little slower than the timed region's); wall minus sum is dispatch gaps "
+                                          "between the five launches of a step"},
         }
         line["rollout_kernel"] = {
             "kernel": f"k_rollout (ppo_rollout_fused), {mode_used}", "bound": "valu-issue",

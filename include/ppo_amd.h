@@ -116,6 +116,24 @@ int ppo_gae_dense(const float *rewards, const float *values, const float *end_va
                   const int *done, const int *trunc, double gamma, double lam, float *adv,
                   float *ret, int T, int N, void *stream);
 
+/*
+ * ppo_gae_dense reading the flags as two BITS per element instead of the two i32 words:
+ *   flag_words [ceil(T/16), N] u32, ppo_gae_flag_words(T, N) words: bits 2k and 2k+1 of word q of column n are
+ *   done and trunc of row 16 q + k (unused high bits of the last word: 0).  ppo_rollout_fused_packed leaves
+ *   them beside its i32 done / trunc buffers, which stay the API's and the reference's format
+ *   (src/ppo.py:393-394).
+ * The same scan (src/ppo.py:452-488) with the same operations and roundings: bit-identical advantages.  12.25 B
+ * of HBM traffic per element (r, v, flag bits read; adv written) instead of 20; end_value_dense is fetched per
+ * row and only by the lanes whose flag word has that row's trunc bit.  Wide batches run the time-split kernel
+ * (four waves per 64 columns, a quarter of the rows each, the one running value handed from wave to wave).
+ * This is the form the trainer's device path uses between the whole-rollout kernel and the update.
+ * Requires N * 4 < 2^32.
+ */
+size_t ppo_gae_flag_words(int T, int N);
+int ppo_gae_dense_packed(const float *rewards, const float *values, const float *end_value_dense,
+                         const uint32_t *flag_words, double gamma, double lam, float *adv, float *ret,
+                         int T, int N, void *stream);
+
 /* Bytes of device workspace ppo_gae_ragged needs for N columns. */
 size_t ppo_gae_ragged_workspace_bytes(int N);
 
@@ -344,6 +362,18 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
                       float *rewards, int *done, int *trunc, float *term_obs, float *ev_dense,
                       double *reward_sum, float *ret_ring, int *len_ring, int *ring_cnt, int ring,
                       int N, int T, void *stream);
+
+/* ppo_rollout_fused that also writes flag_words (ppo_gae_flag_words(T, N) u32, layout as in
+ * ppo_gae_dense_packed): one more store per env and sixteen steps on top of the 40 B per env-step of the
+ * buffers above. */
+int ppo_rollout_fused_packed(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len,
+                             uint32_t *episode, const double *reset_draw, uint64_t seed,
+                             uint64_t env_base, const float *params, int joint, int net_mode,
+                             uint64_t sample_step0,
+                             float *obs_io, float *states, int *actions, float *log_probs, float *values,
+                             float *rewards, int *done, int *trunc, float *term_obs, float *ev_dense,
+                             uint32_t *flag_words, double *reward_sum, float *ret_ring, int *len_ring,
+                             int *ring_cnt, int ring, int N, int T, void *stream);
 
 /*
  * Episode statistics from the device rings.  Replaces the tail of SyncVecEnv.rollout

@@ -21,6 +21,8 @@ SIGNATURES = {
     "ppo_env_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_gae_dense": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _vp]),
+    "ppo_gae_flag_words": (_sz, [_i, _i]),
+    "ppo_gae_dense_packed": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _vp]),
     "ppo_gae_ragged_workspace_bytes": (_sz, [_i]),
     "ppo_gae_ragged": (_i, [_vp, _vp, _vp, _l, _vp, _vp, _d, _d, _vp, _i, _i, _vp, _sz, _vp, _vp]),
     "ppo_gae_ragged_noalloc": (_i, [_vp, _vp, _vp, _l, _vp, _vp, _d, _d, _vp, _i, _i, _vp, _vp]),
@@ -51,13 +53,16 @@ SIGNATURES = {
     "ppo_rollout_pack_params": (_i, [_i, _i, _i] + [_vp] * 14 + [_vp]),
     "ppo_rollout_fused": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ppo_rollout_fused_packed": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 # tuning / test / bench hooks, deliberately not in the public header (listed in INTEGRATION.md)
 _PRIVATE = {
     "ppo_gae_dense_variant": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_stream_ceiling": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "ppo_rollout_fused_ex": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _u64, _vp, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_gae_dense_packed_variant": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_gae_dense_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_prof_arm": (_i, [_i, _i]),
     "ppo_test_acrobot_terminal": (_i, [_vp, _vp, _vp, _l, _vp]),

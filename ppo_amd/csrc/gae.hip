@@ -47,6 +47,7 @@ template <int VEC, int U, bool DENSE_EV> struct RowBlock {
 struct GaeArgs {
     const float *r, *v, *ev;   // ev: dense [T,N] or ragged [E]
     const int *done, *trunc;
+    const uint32_t *flag_words; // packed forms only: [ceil(T/16), N], two bits per element (written by k_rollout)
     float *adv, *ret;
     const long *idx0;          // ragged only: start index per column (cumsum - 1)
     long E;
@@ -347,6 +348,334 @@ template <int VEC, int U, bool NT = false> int launch_gae_sparse(const GaeArgs &
     return ppo_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------
+// Packed-flag forms.  The whole-rollout kernel also leaves the two flags of every element as TWO BITS next to the
+// i32 [T,N] buffers of the API: flag_words [ceil(T/16), N] u32, bits 2k / 2k+1 of word q of column n = done / trunc
+// of row 16 q + k.  The trainer's GAE reads those words instead of the two i32 arrays: r 4 + v 4 + 0.25 read, adv 4
+// written = 12.25 B per element instead of 20, and two load instructions per row instead of four.  End values are
+// fetched per ROW and only by the lanes that hold a truncation in that row (the forced row T-1 is one full row; a
+// TimeLimit hit elsewhere costs one sector).
+//
+// k_gae_tsplit: what bounds the column-per-lane scan is not bytes but loads in flight -- a wave can have 63 vector
+// memory instructions outstanding, a column per lane makes every one of them a 256-byte row segment, and N columns
+// are N/64 waves, so the chip holds at most 63 x 4 B x N = 16 MB in flight whatever the blocking.  Here FOUR waves
+// share 64 columns and each takes a quarter of the rows: the reference's recurrence (src/ppo.py:476-486) has only
+// ONE value that runs through time, adv_t = delta_t + gl (keep_t adv_{t+1}); next_value is just v_{t+1}, so
+// delta_t = r_t + g (keep_t v_{t+1} + trunc_t ev_t) - v_t is computed by all four waves at once, with all their
+// loads in flight together, and only the two-operation chain is handed from wave to wave through LDS (four short
+// phases per 128 rows).  Every operation and its rounding is the reference's; gl * (keep * na) is evaluated as
+// (gl * keep) * na, which is the same f32 for keep in {1, 0, -1}: the inner product is exact either way.
+constexpr int FLAG_ROWS = 16;                       // rows per flag word
+
+template <int VEC> struct WordT;
+template <> struct WordT<1> { using W = uint32_t; };
+template <> struct WordT<2> { using W = __attribute__((ext_vector_type(2))) uint32_t; };
+template <> struct WordT<4> { using W = __attribute__((ext_vector_type(4))) uint32_t; };
+template <int VEC> __device__ __forceinline__ uint32_t wget(const typename WordT<VEC>::W &w, int k)
+{
+    if constexpr (VEC == 1) return w; else return w[k];
+}
+template <int VEC> __device__ __forceinline__ uint32_t wany(const typename WordT<VEC>::W &w)
+{
+    uint32_t x = 0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) x |= wget<VEC>(w, k);
+    return x;
+}
+
+// rows 16 q .. 16 q + 15 of VEC columns
+template <int VEC> struct WordBlock {
+    typename VecT<VEC>::F r[FLAG_ROWS], v[FLAG_ROWS];
+    typename WordT<VEC>::W f;
+};
+template <int VEC> struct EvRows {
+    typename VecT<VEC>::F ev[FLAG_ROWS];
+};
+
+template <int VEC, bool FULL>
+__device__ __forceinline__ void load_word_block(WordBlock<VEC> &b, const GaeArgs &a, size_t col, int q)
+{
+    using F = typename VecT<VEC>::F;
+    b.f = *reinterpret_cast<const typename WordT<VEC>::W *>(a.flag_words + (size_t)q * (size_t)a.N + col);
+#pragma unroll
+    for (int u = FLAG_ROWS - 1; u >= 0; --u) {
+        const int t = q * FLAG_ROWS + u;
+        if (FULL || t < a.T) {
+            const size_t o = (size_t)t * (size_t)a.N + col;
+            b.r[u] = *reinterpret_cast<const F *>(a.r + o);
+            b.v[u] = *reinterpret_cast<const F *>(a.v + o);
+        }
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_ev_word(EvRows<VEC> &e, const WordBlock<VEC> &b, const GaeArgs &a, size_t col, int q)
+{
+    using F = typename VecT<VEC>::F;
+#pragma unroll
+    for (int u = 0; u < FLAG_ROWS; ++u)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) fset<VEC>(e.ev[u], k, 0.0f);
+    const uint32_t tr_bits = wany<VEC>(b.f) & 0xAAAAAAAAu;
+    if (tr_bits) {                                  // rare below the forced last row: one test per 16 rows
+#pragma unroll
+        for (int u = 0; u < FLAG_ROWS; ++u)         // (a set trunc bit always belongs to a row < T)
+            if (tr_bits & (2u << (2 * u)))
+                e.ev[u] = *reinterpret_cast<const F *>(a.ev + (size_t)(q * FLAG_ROWS + u) * (size_t)a.N + col);
+    }
+}
+
+template <int VEC, bool FULL>
+__device__ __forceinline__ void consume_word_block(const WordBlock<VEC> &b, const EvRows<VEC> &e, const GaeArgs &a,
+                                                   size_t col, int q, float (&nv)[VEC], float (&na)[VEC])
+{
+    using F = typename VecT<VEC>::F;
+#pragma unroll
+    for (int u = FLAG_ROWS - 1; u >= 0; --u) {
+        const int t = q * FLAG_ROWS + u;
+        if (!FULL && t >= a.T) continue;
+        F out, rout;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const uint32_t w = wget<VEC>(b.f, k) >> (2 * u);
+            const int d = (int)(w & 1u), tr = (int)((w >> 1) & 1u);
+            const float ev = tr ? fget<VEC>(e.ev[u], k) : 0.0f;
+            const float v = fget<VEC>(b.v[u], k);
+            const float adv = gae_step(fget<VEC>(b.r[u], k), v, d, tr, ev, a.g, a.gl, nv[k], na[k]);
+            fset<VEC>(out, k, adv);
+            fset<VEC>(rout, k, adv + v);
+        }
+        const size_t o = (size_t)t * (size_t)a.N + col;
+        *reinterpret_cast<F *>(a.adv + o) = out;
+        if (a.ret) *reinterpret_cast<F *>(a.ret + o) = rout;
+    }
+}
+
+// Column per lane, one flag word (16 rows) per block, STAGES blocks in flight: the form for narrow batches
+// (too few columns to give four waves per 64 columns something to overlap with) and the tuning baseline.
+template <int VEC, int STAGES, bool FULL>
+__global__ void __launch_bounds__(256) k_gae_words(GaeArgs a)
+{
+    static_assert(STAGES == 2 || STAGES == 3, "");
+    const size_t col = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (col >= (size_t)a.N) return;
+    float nv[VEC], na[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { nv[k] = 0.0f; na[k] = 0.0f; }
+    int q = (a.T + FLAG_ROWS - 1) / FLAG_ROWS - 1;
+    WordBlock<VEC> f0, f1, f2;
+    EvRows<VEC> e0, e1;
+    load_word_block<VEC, FULL>(f0, a, col, q);
+    if (q >= 1) load_word_block<VEC, FULL>(f1, a, col, q - 1);
+    load_ev_word<VEC>(e0, f0, a, col, q);
+    for (; q >= 0; --q) {
+        if (STAGES == 3 && q >= 2) load_word_block<VEC, true>(f2, a, col, q - 2);
+        if (q >= 1) load_ev_word<VEC>(e1, f1, a, col, q - 1);
+        consume_word_block<VEC, FULL>(f0, e0, a, col, q, nv, na);
+        f0 = f1; e0 = e1;
+        if (STAGES == 3) f1 = f2;
+        else if (q >= 2) load_word_block<VEC, true>(f1, a, col, q - 2);
+    }
+}
+
+// Buffer addressing for the time-split kernel: one resource descriptor per array (4 SGPRs), the row's byte offset in
+// an SGPR, the lane's byte offset inside the row in ONE VGPR -- instead of a 64-bit VGPR pair per row in flight.
+// Raw buffer, stride 0, num_records = the array's size in bytes: an access beyond it reads 0 / is dropped.
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufRsrc make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+template <int VEC> __device__ __forceinline__ typename RawT<4 * VEC>::T buf_ld_raw(BufRsrc rs, uint32_t voff, uint32_t soff)
+{
+    if constexpr (VEC == 1) return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+    else if constexpr (VEC == 2) return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    else return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+}
+template <int VEC> __device__ __forceinline__ typename VecT<VEC>::F buf_ld(BufRsrc rs, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(typename VecT<VEC>::F, buf_ld_raw<VEC>(rs, voff, soff));
+}
+template <int VEC> __device__ __forceinline__ void buf_st(BufRsrc rs, uint32_t voff, uint32_t soff, const typename VecT<VEC>::F &x)
+{
+    const auto raw = __builtin_bit_cast(typename RawT<4 * VEC>::T, x);
+    if constexpr (VEC == 1) __builtin_amdgcn_raw_buffer_store_b32(raw, rs, voff, soff, 0);
+    else if constexpr (VEC == 2) __builtin_amdgcn_raw_buffer_store_b64(raw, rs, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff, soff, 0);
+}
+
+// Four waves per 64 * VEC columns, WPW flag words (16 * WPW rows) per wave and pass; see the head of this section.
+template <int VEC, int WPW, bool FULL>
+__global__ void __launch_bounds__(256) k_gae_tsplit(GaeArgs a)
+{
+    using F = typename VecT<VEC>::F;
+    using W = typename WordT<VEC>::W;
+    constexpr int R = FLAG_ROWS * WPW;
+    __shared__ float carry[VEC][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t col = ((size_t)blockIdx.x * 64 + lane) * VEC;
+    const bool live = col < (size_t)a.N;            // (no early return: every wave takes part in the barriers)
+    const uint32_t off = (uint32_t)col * 4u;        // byte offset inside a row (the host checks N * 4 < 2^32)
+    const uint32_t stride = (uint32_t)a.N * 4u;     // bytes per row (the host checks T * N * 4 < 2^32)
+    const int words = (a.T + FLAG_ROWS - 1) / FLAG_ROWS;
+    const uint32_t bytes = (uint32_t)a.T * stride;
+    const BufRsrc rs_r = make_rsrc(a.r, bytes), rs_v = make_rsrc(a.v, bytes), rs_ev = make_rsrc(a.ev, bytes);
+    const BufRsrc rs_f = make_rsrc(a.flag_words, (uint32_t)words * stride);
+    const BufRsrc rs_adv = make_rsrc(a.adv, bytes), rs_ret = make_rsrc(a.ret, a.ret ? bytes : 0u);
+    auto row = [&](int t) { return (uint32_t)t * stride; };
+    bool first = true;                              // nothing has been scanned yet: advantages start from 0 (:471)
+    for (int qtop = words - 1; qtop >= 0; qtop -= 4 * WPW) {
+        const int q_hi = qtop - w * WPW;            // this wave's words: q_hi, q_hi - 1, .. (those >= 0)
+        F r[R], v[R], ev[R];
+        W f[WPW];
+        F v_above;                                  // values of the row above this wave's top row: its next_value (:485)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) fset<VEC>(v_above, k, 0.0f);
+        if (live && q_hi >= 0) {
+            const int t_above = (q_hi + 1) * FLAG_ROWS;
+            if (t_above < a.T) v_above = buf_ld<VEC>(rs_v, off, row(t_above));
+#pragma unroll
+            for (int j = 0; j < WPW; ++j) {
+                const int q = q_hi - j;
+                if (q < 0) continue;
+                f[j] = __builtin_bit_cast(W, buf_ld_raw<VEC>(rs_f, off, row(q)));
+#pragma unroll
+                for (int u = FLAG_ROWS - 1; u >= 0; --u) {
+                    const int t = q * FLAG_ROWS + u, i = j * FLAG_ROWS + (FLAG_ROWS - 1 - u);   // i: top row first
+                    if (FULL || t < a.T) {
+                        r[i] = buf_ld<VEC>(rs_r, off, row(t));
+                        v[i] = buf_ld<VEC>(rs_v, off, row(t));
+                    }
+                }
+            }
+            // end values of this wave's truncated cells
+#pragma unroll
+            for (int j = 0; j < WPW; ++j) {
+                const int q = q_hi - j;
+                if (q < 0) continue;
+                const uint32_t tr_bits = wany<VEC>(f[j]) & 0xAAAAAAAAu;
+#pragma unroll
+                for (int u = FLAG_ROWS - 1; u >= 0; --u) {
+                    const int i = j * FLAG_ROWS + (FLAG_ROWS - 1 - u);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) fset<VEC>(ev[i], k, 0.0f);
+                }
+                if (tr_bits) {
+#pragma unroll
+                    for (int u = FLAG_ROWS - 1; u >= 0; --u)
+                        if (tr_bits & (2u << (2 * u)))
+                            ev[j * FLAG_ROWS + (FLAG_ROWS - 1 - u)] = buf_ld<VEC>(rs_ev, off, row(q * FLAG_ROWS + u));
+                }
+            }
+            // delta_t of every row (:476-482), all four waves at once; r[i] <- delta
+#pragma unroll
+            for (int j = 0; j < WPW; ++j) {
+                const int q = q_hi - j;
+                if (q < 0) continue;
+#pragma unroll
+                for (int u = FLAG_ROWS - 1; u >= 0; --u) {
+                    const int t = q * FLAG_ROWS + u, i = j * FLAG_ROWS + (FLAG_ROWS - 1 - u);
+                    if (!FULL && t >= a.T) continue;
+                    F delta;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const uint32_t fw = wget<VEC>(f[j], k) >> (2 * u);
+                        const int d = (int)(fw & 1u), tr = (int)((fw >> 1) & 1u);
+                        const float keep = (float)(1 - (d + tr));                               // :476-477
+                        // the row above: v[i - 1], or v_above for the wave's top row (rows >= T do not exist: the
+                        // top row of the rollout sees next_value = 0, :470)
+                        float nv;
+                        if (i == 0) nv = fget<VEC>(v_above, k);
+                        else nv = (FULL || t + 1 < a.T) ? fget<VEC>(v[i - 1], k) : 0.0f;
+                        const float e = tr ? fget<VEC>(ev[i], k) : 0.0f;
+                        nv = keep * nv + (float)tr * e;                                         // :478
+                        fset<VEC>(delta, k, fget<VEC>(r[i], k) + a.g * nv - fget<VEC>(v[i], k));   // :482
+                    }
+                    r[i] = delta;
+                }
+            }
+        }
+        // the chain through time, a wave at a time, latest rows first
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {
+            if (p == w && live && q_hi >= 0) {
+                float na[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) na[k] = first && w == 0 ? 0.0f : carry[k][lane];
+#pragma unroll
+                for (int j = 0; j < WPW; ++j) {
+                    const int q = q_hi - j;
+                    if (q < 0) continue;
+#pragma unroll
+                    for (int u = FLAG_ROWS - 1; u >= 0; --u) {
+                        const int t = q * FLAG_ROWS + u, i = j * FLAG_ROWS + (FLAG_ROWS - 1 - u);
+                        if (!FULL && t >= a.T) continue;
+                        F out, rout;
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            const uint32_t fw = wget<VEC>(f[j], k) >> (2 * u);
+                            const float keep = (float)(1 - (int)((fw & 1u) + ((fw >> 1) & 1u)));
+                            const float c = a.gl * keep;                                        // exact: keep in {1, 0, -1}
+                            const float adv = fget<VEC>(r[i], k) + c * na[k];                   // :479, :483
+                            na[k] = adv;                                                        // :486
+                            fset<VEC>(out, k, adv);
+                            fset<VEC>(rout, k, adv + fget<VEC>(v[i], k));
+                        }
+                        buf_st<VEC>(rs_adv, off, row(t), out);
+                        if (a.ret) buf_st<VEC>(rs_ret, off, row(t), rout);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) carry[k][lane] = na[k];
+            }
+            __syncthreads();
+        }
+        first = false;
+    }
+}
+
+template <int VEC, int STAGES> int launch_gae_words(const GaeArgs &a, hipStream_t s)
+{
+    const long threads = a.N / VEC;
+    const int block = (threads + 63) / 64 <= 2048 ? 64 : 256;
+    const long grid = (threads + block - 1) / block;
+    if (a.T % FLAG_ROWS == 0) PPO_LAUNCH((k_gae_words<VEC, STAGES, true>), dim3((unsigned)grid), dim3(block), s, a);
+    else PPO_LAUNCH((k_gae_words<VEC, STAGES, false>), dim3((unsigned)grid), dim3(block), s, a);
+    return ppo_launch_status();
+}
+
+template <int VEC, int WPW> int launch_gae_tsplit(const GaeArgs &a, hipStream_t s)
+{
+    if ((size_t)a.T * (size_t)a.N * 4 >= ((size_t)1 << 32)) return launch_gae_words<VEC, 2>(a, s);   // 32-bit row offsets
+    const long grid = (a.N / VEC + 63) / 64;
+    if (a.T % FLAG_ROWS == 0) PPO_LAUNCH((k_gae_tsplit<VEC, WPW, true>), dim3((unsigned)grid), dim3(256), s, a);
+    else PPO_LAUNCH((k_gae_tsplit<VEC, WPW, false>), dim3((unsigned)grid), dim3(256), s, a);
+    return ppo_launch_status();
+}
+
+// Variant table of the packed forms (tools/tune_gae_packed.py; numbers in DESIGN.md)
+int launch_gae_packed_variant(const GaeArgs &a, int variant, hipStream_t s)
+{
+    switch (variant) {
+    case 0: return launch_gae_words<1, 3>(a, s);
+    case 1: return launch_gae_words<2, 2>(a, s);
+    case 2: return launch_gae_words<1, 2>(a, s);
+    case 3: return launch_gae_tsplit<1, 2>(a, s);
+    case 4: return launch_gae_tsplit<1, 1>(a, s);
+    case 5: return launch_gae_tsplit<2, 1>(a, s);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+int packed_variant_vec(int variant)
+{
+    switch (variant) {
+    case 1: case 5: return 2;
+    default: return 1;
+    }
+}
+
 // A pure streaming kernel with the GAE traffic mix (5 x 4 B read, 4 B written per element,
 // 16 B per lane, full occupancy): the measured ceiling the scan kernels are compared to.
 __global__ void __launch_bounds__(256) k_stream_ceiling(const float4 *r, const float4 *v, const float4 *ev,
@@ -520,7 +849,7 @@ static int gae_dense_launch(const float *rewards, const float *values, const flo
     PPO_REQUIRE(ppo_aligned(rewards, al) && ppo_aligned(values, al) && ppo_aligned(end_value_dense, al) &&
                 ppo_aligned(done, al) && ppo_aligned(trunc, al) && ppo_aligned(adv, al) &&
                 (!ret || ppo_aligned(ret, al)));
-    GaeArgs a{rewards, values, end_value_dense, done, trunc, adv, ret, nullptr, 0, nullptr,
+    GaeArgs a{rewards, values, end_value_dense, done, trunc, nullptr, adv, ret, nullptr, 0, nullptr,
               (float)gamma, (float)(gamma * lam), T, N};
     return launch_gae_dense_variant(a, variant, (hipStream_t)stream);
 }
@@ -551,6 +880,55 @@ int ppo_gae_dense(const float *rewards, const float *values, const float *end_va
     PPO_REQUIRE(rewards && values && end_value_dense && done && trunc && adv);
     return gae_dense_launch(rewards, values, end_value_dense, done, trunc, gamma, lam, adv, ret, T, N,
                             gae_default_variant(rewards, values, end_value_dense, done, trunc, adv, ret, N), stream);
+}
+
+// ---- packed-flag forms (see k_gae_tsplit) ------------------------------------------------------
+static int gae_packed_launch(const float *rewards, const float *values, const float *end_value_dense,
+                             const uint32_t *flag_words, double gamma, double lam, float *adv, float *ret, int T, int N,
+                             int variant, void *stream)
+{
+    PPO_REQUIRE(rewards && values && end_value_dense && flag_words && adv);
+    PPO_REQUIRE(T >= 0 && N >= 0);
+    if (T == 0 || N == 0) return 0;
+    const int vec = packed_variant_vec(variant);
+    const size_t al = 4 * (size_t)vec;
+    PPO_REQUIRE(N % vec == 0 && (size_t)N * 4 < ((size_t)1 << 32));
+    PPO_REQUIRE(ppo_aligned(rewards, al) && ppo_aligned(values, al) && ppo_aligned(end_value_dense, al) &&
+                ppo_aligned(flag_words, al) && ppo_aligned(adv, al) && (!ret || ppo_aligned(ret, al)));
+    GaeArgs a{rewards, values, end_value_dense, nullptr, nullptr, flag_words, adv, ret, nullptr, 0, nullptr,
+              (float)gamma, (float)(gamma * lam), T, N};
+    return launch_gae_packed_variant(a, variant, (hipStream_t)stream);
+}
+
+// Tuning hook (not part of the public header)
+int ppo_gae_dense_packed_variant(const float *rewards, const float *values, const float *end_value_dense,
+                                 const uint32_t *flag_words, double gamma, double lam, float *adv, float *ret, int T,
+                                 int N, int variant, void *stream)
+{
+    return gae_packed_launch(rewards, values, end_value_dense, flag_words, gamma, lam, adv, ret, T, N, variant, stream);
+}
+
+size_t ppo_gae_flag_words(int T, int N)
+{
+    return T > 0 && N > 0 ? (size_t)((T + FLAG_ROWS - 1) / FLAG_ROWS) * (size_t)N : 0;
+}
+
+int ppo_gae_dense_packed(const float *rewards, const float *values, const float *end_value_dense,
+                         const uint32_t *flag_words, double gamma, double lam, float *adv, float *ret, int T, int N,
+                         void *stream)
+{
+    PPO_REQUIRE(rewards && values && end_value_dense && flag_words && adv);
+    PPO_REQUIRE(ppo_aligned(rewards, 4) && ppo_aligned(values, 4) && ppo_aligned(end_value_dense, 4) &&
+                ppo_aligned(flag_words, 4) && ppo_aligned(adv, 4) && (!ret || ppo_aligned(ret, 4)));
+    // Measured (profiles/r03_gae_packed_variants.txt).  Narrow batches are too few waves for a column per lane to keep
+    // the memory system busy: the time-split kernel gives them four waves per 64 columns (13.0 vs 15.1 us at
+    // [128, 16384], 19.5 vs 26.6 at [256, 4096], 139 vs 198 at [2048, 1024]); at 65536 columns the column-per-lane
+    // form is ahead (23.6 vs 28.8 us on HBM-cold inputs), from 131072 on with two columns per lane (77 vs 87 us at
+    // [128, 262144]).
+    const bool even = (N % 2 == 0) && ppo_aligned(rewards, 8) && ppo_aligned(values, 8) && ppo_aligned(end_value_dense, 8) &&
+                      ppo_aligned(flag_words, 8) && ppo_aligned(adv, 8) && (!ret || ppo_aligned(ret, 8));
+    const int variant = N <= 8192 ? 3 : N <= 32768 ? 4 : (N >= 131072 && even) ? 1 : 0;
+    return gae_packed_launch(rewards, values, end_value_dense, flag_words, gamma, lam, adv, ret, T, N, variant, stream);
 }
 
 // Bench-only (private): the next `count` kernel launches of this library are timed into event slots
@@ -647,7 +1025,7 @@ int ppo_gae_ragged(const float *rewards, const float *values, const float *end_v
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(RAG_BLOCK), 0, s, idx0, totals, N);
     rc = ppo_launch_status();
     if (rc) return rc;
-    GaeArgs a{rewards, values, end_values, done, trunc, adv, nullptr, idx0, E, err_flag,
+    GaeArgs a{rewards, values, end_values, done, trunc, nullptr, adv, nullptr, idx0, E, err_flag,
               (float)gamma, (float)(gamma * lam), T, N};
     return launch_gae<1, 8, false>(a, s);
 }

@@ -63,6 +63,7 @@ struct RolloutArgs {
     int *actions;            // [T,N]
     float *log_probs, *values, *rewards;  // [T,N]
     int *done, *trunc;       // [T,N]
+    uint32_t *flag_words;    // [ceil(T/16),N] or NULL: bits 2k / 2k+1 of word q = done / trunc of row 16 q + k (ppo_gae_dense_packed)
     float *term_obs;         // [T,N,OBS], written where a flag is raised
     float *ev_dense;         // [T,N] or NULL: V(terminal obs) written where trunc != 0
     double *reward_sum;      // or NULL: += sum of all rewards of this rollout (one f64 atomic per wave)
@@ -607,6 +608,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     };
     SampleDraws draws;
     draws.w0 = draws.w1 = draws.w2 = 0u;
+    uint32_t flag_bits = 0u;
     for (int t = 0; t < a.T; ++t) {
         StepOut o;
         o.trunc = 0;
@@ -661,6 +663,11 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
             rsum += o.reward;
             a.done[row] = o.done;
             a.trunc[row] = o.trunc;
+            flag_bits |= (uint32_t)(o.done | (o.trunc << 1)) << (2 * (t & 15));
+            if ((t & 15) == 15 || t == a.T - 1) {   // sixteen steps of flags per word
+                if (a.flag_words) a.flag_words[(size_t)(t >> 4) * N + n] = flag_bits;
+                flag_bits = 0u;
+            }
             if (o.done + o.trunc > 0) store_obs<Env>(a.term_obs, row, o.term);
         }
         const bool need_ev = a.ev_dense != nullptr && live && o.trunc > 0;
@@ -750,8 +757,8 @@ int ppo_rollout_fused_ex(int kind, double *state, int *elapsed, float *ep_ret, i
                          const double *reset_draw, uint64_t seed, uint64_t env_base, const float *params,
                          int joint, int net_mode, uint64_t sample_step0, float *obs_io, float *states, int *actions,
                          float *log_probs, float *values, float *rewards, int *done, int *trunc, float *term_obs,
-                         float *ev_dense, double *reward_sum, float *ret_ring, int *len_ring, int *ring_cnt, int ring,
-                         int N, int T, int wave_envs, void *stream)
+                         float *ev_dense, uint32_t *flag_words, double *reward_sum, float *ret_ring, int *len_ring, int *ring_cnt,
+                         int ring, int N, int T, int wave_envs, void *stream)
 {
     PPO_REQUIRE(wave_envs == 0 || wave_envs == 32 || wave_envs == 64);
     PPO_REQUIRE(kind == PPO_ENV_CARTPOLE || kind == PPO_ENV_ACROBOT);
@@ -774,7 +781,7 @@ int ppo_rollout_fused_ex(int kind, double *state, int *elapsed, float *ep_ret, i
     a.env.N = N;
     a.params = params; a.sample_step0 = sample_step0; a.obs_io = obs_io; a.states = states; a.actions = actions;
     a.log_probs = log_probs; a.values = values; a.rewards = rewards; a.done = done; a.trunc = trunc;
-    a.term_obs = term_obs; a.ev_dense = ev_dense; a.reward_sum = reward_sum; a.T = T;
+    a.term_obs = term_obs; a.ev_dense = ev_dense; a.flag_words = flag_words; a.reward_sum = reward_sum; a.T = T;
 #ifdef PPO_ROLLOUT_ABLATE_BUILD
     static const int ablate_env = [] { const char *e = getenv("PPO_ROLLOUT_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate_env;                          // diagnostic builds only; read once
@@ -793,7 +800,22 @@ int ppo_rollout_fused(int kind, double *state, int *elapsed, float *ep_ret, int 
 {
     return ppo_rollout_fused_ex(kind, state, elapsed, ep_ret, ep_len, episode, reset_draw, seed, env_base, params, joint,
                                 net_mode, sample_step0, obs_io, states, actions, log_probs, values, rewards, done, trunc,
-                                term_obs, ev_dense, reward_sum, ret_ring, len_ring, ring_cnt, ring, N, T, 0, stream);
+                                term_obs, ev_dense, nullptr, reward_sum, ret_ring, len_ring, ring_cnt, ring, N, T, 0, stream);
+}
+
+// ppo_rollout_fused that also leaves the packed flag words for ppo_gae_dense_packed
+int ppo_rollout_fused_packed(int kind, double *state, int *elapsed, float *ep_ret, int *ep_len, uint32_t *episode,
+                             const double *reset_draw, uint64_t seed, uint64_t env_base, const float *params,
+                             int joint, int net_mode, uint64_t sample_step0, float *obs_io, float *states, int *actions,
+                             float *log_probs, float *values, float *rewards, int *done, int *trunc, float *term_obs,
+                             float *ev_dense, uint32_t *flag_words, double *reward_sum, float *ret_ring, int *len_ring,
+                             int *ring_cnt, int ring, int N, int T, void *stream)
+{
+    PPO_REQUIRE(flag_words || N == 0 || T == 0);
+    PPO_REQUIRE(ppo_aligned(flag_words, 4));
+    return ppo_rollout_fused_ex(kind, state, elapsed, ep_ret, ep_len, episode, reset_draw, seed, env_base, params, joint,
+                                net_mode, sample_step0, obs_io, states, actions, log_probs, values, rewards, done, trunc,
+                                term_obs, ev_dense, flag_words, reward_sum, ret_ring, len_ring, ring_cnt, ring, N, T, 0, stream);
 }
 
 }  // extern "C"

@@ -79,6 +79,51 @@ def gae_dense(rewards, values, end_value_dense, done_flags, trunc_flags, gamma, 
     return (adv, ret) if want_returns else adv
 
 
+def gae_flag_words(T: int, N: int, device) -> torch.Tensor:
+    """The [ceil(T/16), N] u32 (held as int32) flag-word buffer of ppo_rollout_fused_packed / ppo_gae_dense_packed."""
+    n = _lib.load().ppo_gae_flag_words(int(T), int(N))
+    return torch.empty((n // max(N, 1), N), dtype=torch.int32, device=device)
+
+
+def pack_flag_words(done_flags, trunc_flags) -> torch.Tensor:
+    """[T,N] i32 done / trunc (values 0 / 1) -> flag words, on the tensors' device (tests and tools: the rollout
+    kernel writes the words itself)."""
+    T, N = done_flags.shape
+    code = (done_flags.to(torch.int64) | (trunc_flags.to(torch.int64) << 1))
+    rows = (T + 15) // 16 * 16
+    if rows != T:
+        code = torch.cat([code, torch.zeros((rows - T, N), dtype=torch.int64, device=code.device)])
+    shifts = (2 * torch.arange(16, device=code.device, dtype=torch.int64)).view(1, 16, 1)
+    words = (code.view(rows // 16, 16, N) << shifts).sum(1)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()   # the u32 bit pattern
+
+
+def gae_dense_packed(rewards, values, end_value_dense, flag_words, gamma, lam, want_returns=False, out=None, variant=None,
+                     prof_slot=None):
+    """ppo_gae_dense_packed: the scan of reference src/ppo.py:452-488 reading the two flag bits per element the
+    whole-rollout kernel leaves; device tensors only.  prof_slot (bench only): time the dispatch into that slot."""
+    lib = _lib.load()
+    T, N = rewards.shape
+    for x in (rewards, values, end_value_dense):
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape == (T, N) and x.is_contiguous(), (x.dtype, x.shape)
+    assert flag_words.is_cuda and flag_words.dtype == torch.int32 and flag_words.is_contiguous()
+    assert flag_words.shape == ((T + 15) // 16, N), (flag_words.shape, T, N)
+    adv = out if out is not None else torch.empty((T, N), dtype=torch.float32, device=rewards.device)
+    ret = torch.empty((T, N), dtype=torch.float32, device=rewards.device) if want_returns else None
+    args = (_ptr(rewards), _ptr(values), _ptr(end_value_dense), _ptr(flag_words), float(gamma), float(lam), _ptr(adv),
+            _ptr(ret), T, N)
+    if prof_slot is not None:
+        _lib.check(lib.ppo_prof_arm(int(prof_slot), 1), "ppo_prof_arm")
+    if variant is None:
+        rc = lib.ppo_gae_dense_packed(*args, _stream())
+    else:
+        rc = lib.ppo_gae_dense_packed_variant(*args, int(variant), _stream())
+    if prof_slot is not None:
+        lib.ppo_prof_arm(int(prof_slot), 0)     # (an argument check may have returned before the launch)
+    _lib.check(rc, "ppo_gae_dense_packed")
+    return (adv, ret) if want_returns else adv
+
+
 def gae_ragged(rewards, values, end_values, done_flags, trunc_flags, gamma, lam, check_index=True, noalloc=False,
                out=None, err=None):
     """ppo_gae_ragged: exact drop-in for PPO.compute_advantages (reference src/ppo.py:452-488).
@@ -440,8 +485,9 @@ def resolve_net_mode(agent, net_mode: int):
 
 
 def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, log_probs, values, rewards, done,
-                  trunc, term_obs, ev_dense, T, net_mode: int = NET_F32, reward_sum=None, wave_envs: int = 0):
+                  trunc, term_obs, ev_dense, T, net_mode: int = NET_F32, reward_sum=None, wave_envs: int = 0, flag_words=None):
     """ppo_rollout_fused over a ppo_amd.envs.DeviceEnvBatch; every tensor is written in place.
+    flag_words (gae_flag_words(T, N)): also leave the packed flag bits (ppo_rollout_fused_packed).
     wave_envs != 0 (tests / tuning) forces 32 or 64 envs per wave through the private _ex entry."""
     lib = _lib.load()
     need = rollout_param_floats(batch.kind, int(bool(joint)), int(net_mode))
@@ -451,11 +497,17 @@ def rollout_fused(batch, params, joint, sample_step0, obs_io, states, actions, l
         batch.kind, bp[0], bp[1], bp[2], bp[3], bp[4], None, batch.seed, batch.env_base, params.data_ptr(),
         int(bool(joint)), int(net_mode), int(sample_step0), obs_io.data_ptr(), states.data_ptr(), actions.data_ptr(),
         log_probs.data_ptr(), values.data_ptr(), rewards.data_ptr(), done.data_ptr(), trunc.data_ptr(),
-        term_obs.data_ptr(), _ptr(ev_dense), _ptr(reward_sum), bp[5], bp[6], bp[7],
-        batch.ring, batch.num_envs, int(T))
+        term_obs.data_ptr(), _ptr(ev_dense))
+    tail = (_ptr(reward_sum), bp[5], bp[6], bp[7], batch.ring, batch.num_envs, int(T))
+    if flag_words is not None:
+        assert flag_words.is_cuda and flag_words.dtype == torch.int32 and flag_words.is_contiguous()
+        assert flag_words.shape == ((int(T) + 15) // 16, batch.num_envs)
     if wave_envs:
-        rc = lib.ppo_rollout_fused_ex(*args, int(wave_envs), _stream())
+        rc = lib.ppo_rollout_fused_ex(*args, _ptr(flag_words), *tail, int(wave_envs), _stream())
+    elif flag_words is not None:
+        rc = lib.ppo_rollout_fused_packed(*args, flag_words.data_ptr(), *tail, _stream())
     else:
+        args = args + tail
         rc = lib.ppo_rollout_fused(*args, _stream())
     _lib.check(rc, "ppo_rollout_fused")
 

@@ -227,6 +227,7 @@ class SyncVecEnv:
             self.envs = [first]
             self._term_obs = None
             self._ev_dense = None
+            self._flag_words = None                    # [ceil(T/16),N]: two flag bits per element, what the packed GAE kernel reads
         else:
             self.batch, self.kdev = None, None
             self.envs = [first] + [env_fn() for _ in range(num_envs - 1)]
@@ -331,6 +332,8 @@ class SyncVecEnv:
         if whole:
             if self._ev_dense is None or self._ev_dense.shape != self.rewards.shape:
                 self._ev_dense = torch.empty_like(self.rewards)
+            if self._flag_words is None or self._flag_words.shape != ((T + 15) // 16, N):
+                self._flag_words = ops.gae_flag_words(T, N, kdev)
             carry = self.t_states.contiguous()         # obs_io: read at t = 0, overwritten with the carried obs
             # reward-sum cell of this rollout (read lazily later): cells come zeroed 64 at a time, so
             # that a rollout does not pay for a fill launch of its own
@@ -342,7 +345,7 @@ class SyncVecEnv:
             ops.rollout_fused(b, params, self.agent.joint_net, self._rollouts * T, carry,
                               self.states, self.actions, self.log_probs, self.values, self.rewards,
                               self.done_flags, self.trunc_flags, self._term_obs, self._ev_dense, T,
-                              net_mode=mode, reward_sum=rsum, wave_envs=self.wave_envs)
+                              net_mode=mode, reward_sum=rsum, wave_envs=self.wave_envs, flag_words=self._flag_words)
             self.net_mode_used = mode
             self._ev_ready = True                      # bootstrap values already written by the kernel
         else:
@@ -1040,8 +1043,8 @@ class PPO:
     def _rollout_advantages(self, ve: SyncVecEnv) -> torch.Tensor:
         """Bootstrap values + GAE for the rollout just collected (reference src/ppo.py:554-557)."""
         if getattr(ve, "_ev_ready", False):   # whole-rollout kernel already wrote V(terminal obs) where trunc != 0
-            return ops.gae_dense(ve.rewards, ve.values, ve._ev_dense, ve.done_flags, ve.trunc_flags,
-                                 self.discount_factor, self.gae_factor)
+            return ops.gae_dense_packed(ve.rewards, ve.values, ve._ev_dense, ve._flag_words,
+                                        self.discount_factor, self.gae_factor)
         end_values = self.agent.get_values(ve.end_states)
         return self._advantages(ve, end_values)
 

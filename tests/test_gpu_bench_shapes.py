@@ -113,6 +113,10 @@ def test_fused_rollout_at_benchmarked_shape(kind, N, mode):
 
         # (iii) GAE on the kernel's own buffers
         adv = ops.gae_dense(ve.rewards, ve.values, ve._ev_dense, done, trunc, 0.99, 0.95)
+        # the packed flag words the kernel leaves for the trainer's GAE are the two i32 buffers, and that form's
+        # advantages (what PPO._rollout_advantages computes) are the same bits
+        assert torch.equal(ve._flag_words, ops.pack_flag_words(done, trunc))
+        assert torch.equal(ops.gae_dense_packed(ve.rewards, ve.values, ve._ev_dense, ve._flag_words, 0.99, 0.95), adv)
         evz = torch.where(trm, ve._ev_dense, torch.zeros_like(ve._ev_dense))   # defined only where trunc != 0
 
         for s0, n, ora in oracles:

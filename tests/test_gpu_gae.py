@@ -96,6 +96,79 @@ def test_dense_vs_oracle_all_variants(T, N):
         assert np.array_equal(got.cpu().numpy(), want), f"variant {variant}"
 
 
+PACKED_VARIANTS = {0: 1, 1: 2, 2: 1, 3: 1, 4: 1, 5: 2}   # variant -> columns per lane (3..5: time-split kernel)
+
+
+def _pack_words_np(d, tr):
+    T, N = d.shape
+    words = np.zeros(((T + 15) // 16, N), dtype=np.uint32)
+    for t in range(T):
+        words[t // 16] |= (d[t] | (tr[t] << 1)).astype(np.uint32) << np.uint32(2 * (t % 16))
+    return words.view(np.int32)
+
+
+@pytest.mark.parametrize("T,N", [(1, 1), (7, 3), (8, 64), (128, 64), (125, 4), (256, 33), (33, 1000), (16, 4096), (100, 260), (65, 4100),
+                                 (128, 8192), (256, 4096), (129, 512), (300, 128), (64, 2)])
+def test_packed_flag_forms_vs_oracle_all_variants(T, N):
+    """ppo_gae_dense_packed (two flag bits per element; column-per-lane and time-split kernels): bit-exact against
+    the oracle's scan of src/ppo.py:452-488 in every instantiation, NaN in the unflagged end values not leaking."""
+    from ppo_amd import _lib, ops
+    rng = np.random.default_rng(T * 1000 + N + 1)
+    r, v, ev, d, tr = rand_case(rng, T, N, 0.05, 0.02)
+    want, want_ret = cref.gae_dense(r, v, ev, d, tr, 0.99, 0.95, want_returns=True)
+    ev_nan = np.where(tr != 0, ev, np.nan).astype(np.float32)
+    words = _pack_words_np(d, tr)
+    assert np.array_equal(ops.pack_flag_words(torch.from_numpy(d), torch.from_numpy(tr)).numpy(), words)
+    dev = [torch.from_numpy(x).cuda() for x in (r, v, ev_nan, words)]
+    got, ret = ops.gae_dense_packed(*dev, 0.99, 0.95, want_returns=True)
+    assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(ret.cpu().numpy(), want_ret)
+    for variant, vec in PACKED_VARIANTS.items():
+        if N % vec:
+            with pytest.raises(_lib.PpoAmdError):
+                ops.gae_dense_packed(*dev, 0.99, 0.95, variant=variant)
+            continue
+        got, ret = ops.gae_dense_packed(*dev, 0.99, 0.95, variant=variant, want_returns=True)
+        assert np.array_equal(got.cpu().numpy(), want), f"variant {variant}"
+        assert np.array_equal(ret.cpu().numpy(), want_ret), f"variant {variant} (returns)"
+
+
+def test_packed_flag_form_keeps_the_reference_arithmetic_on_special_values():
+    """Signed zeros, infinities and NaN go through the scan as in the reference (0 * inf = NaN across an episode
+    boundary, -0 preserved): the time-split kernel evaluates gl * (keep * na) as (gl * keep) * na, which must be the
+    same f32 in every such case."""
+    from ppo_amd import ops
+    rng = np.random.default_rng(3)
+    T, N = 64, 256
+    r, v, ev, d, tr = rand_case(rng, T, N, 0.1, 0.05)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e38, -1e38, 1e-45], dtype=np.float32)
+    for x in (r, v, ev):
+        mask = rng.random((T, N)) < 0.05
+        x[mask] = special[rng.integers(0, len(special), int(mask.sum()))]
+    with np.errstate(all="ignore"):
+        want = cref.gae_dense(r, v, ev, d, tr, 0.99, 0.95)
+    dev = [torch.from_numpy(x).cuda() for x in (r, v, ev, _pack_words_np(d, tr))]
+    for variant in PACKED_VARIANTS:
+        got = ops.gae_dense_packed(*dev, 0.99, 0.95, variant=variant).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32) & 0x7FC00000 == 0x7FC00000, np.isnan(want)), variant   # NaN where the oracle has NaN
+        ok = ~np.isnan(want)
+        assert np.array_equal(got.view(np.uint32)[ok], want.view(np.uint32)[ok]), variant               # same bits elsewhere (incl. -0)
+
+
+def test_packed_flag_form_rejects_bad_arguments():
+    from ppo_amd import _lib, ops
+    lib = _lib.load()
+    x = torch.zeros(8, 64, device="cuda")
+    f = torch.zeros(1, 64, dtype=torch.int32, device="cuda")
+    p = lambda t: t.data_ptr()
+    assert lib.ppo_gae_flag_words(8, 64) == 64 and lib.ppo_gae_flag_words(17, 3) == 6 and lib.ppo_gae_flag_words(0, 5) == 0
+    assert lib.ppo_gae_dense_packed(p(x), p(x), p(x), None, 0.99, 0.95, p(x), None, 8, 64, None) == 1
+    assert lib.ppo_gae_dense_packed(p(x), p(x), p(x), p(f), 0.99, 0.95, p(x), None, -1, 64, None) == 1
+    assert lib.ppo_gae_dense_packed(p(x), p(x), p(x), p(f) + 2, 0.99, 0.95, p(x), None, 8, 64, None) == 1   # misaligned words
+    assert lib.ppo_gae_dense_packed(p(x), p(x), p(x), p(f), 0.99, 0.95, p(x), None, 0, 64, None) == 0   # empty: nothing to do
+    with pytest.raises(AssertionError):
+        ops.gae_dense_packed(x, x, x, torch.zeros(8, 64, dtype=torch.int32, device="cuda"), 0.99, 0.95)   # wrong word count
+
+
 def test_dense_ignores_unflagged_end_values():
     """The dense bootstrap buffer is only defined where trunc is set: NaN elsewhere must not leak."""
     from ppo_amd import ops
