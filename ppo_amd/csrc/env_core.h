@@ -231,15 +231,19 @@ struct Acrobot {
     // observation's own sin / cos (angle-sum identity) saves a trigonometric reduction per step and agrees with
     // the direct value to a few 1e-16 -- so the identity DECIDES only where it cannot be wrong: outside a band of
     // 1e-9 around the threshold, a million times its worst-case error.  Inside the band the reference's own
-    // expression is evaluated, so the flag is, structurally, that expression's (wave-uniform branch; taken by
-    // about one step in 10^9).
+    // expression is evaluated -- cos(theta1 + theta2) of the summed angle; t.c1 IS cos(s[0]), the library's sincos
+    // and cos share reduction and polynomial -- so the flag is, structurally, that expression's (wave-uniform
+    // branch; taken by about one step in 10^9).  Price, measured (profiles/r03_acrobot_guard_band_ab.txt): 8 us of
+    // a 701 us rollout at N = 65536, T = 128 -- the branch splits a scheduling region; the cosine itself never runs.
     __device__ static bool terminal(const double (&s)[4], const Trig &t)
     {
         const double lhs = -t.c1 - __builtin_fma(t.c1, t.c2, -(t.s1 * t.s2));
         bool terminated = lhs > 1.0;
+#ifndef PPO_ACROBOT_NO_GUARD_BAND                     // (tools/build_variant.sh: the A/B build that prices the band)
         if (__any(fabs(lhs - 1.0) < 1e-9)) {
-            if (fabs(lhs - 1.0) < 1e-9) terminated = (-cos(s[0]) - cos(s[1] + s[0]) > 1.0);
+            if (fabs(lhs - 1.0) < 1e-9) terminated = (-t.c1 - cos(s[1] + s[0]) > 1.0);
         }
+#endif
         return terminated;
     }
 };
