@@ -421,7 +421,9 @@ def main():
                                  "input, written by the rollout kernel just before, is served by the 256 MiB Infinity "
                                  "Cache; with HBM-cold inputs (profiles/r03_gae_packed_variants.txt) the kernel takes "
                                  "23.6 us, and `traffic` is the L2-to-fabric byte count of such a cold launch"},
-            "step_breakdown_us": {"episode_statistics_3_kernels": float(stats_us), "k_rollout": float(ro_us),
+            "step_breakdown_us": {"episode_statistics_3_kernels": float(stats_us),
+                                  "episode_statistics_each": [float(x) for x in per_kernel[:, :3].mean(0)],
+                                  "k_rollout": float(ro_us),
                                   "k_gae": float(gae_bd_us), "sum": float(stats_us + ro_us + gae_bd_us),
                                   "wall_per_step_of_these_steps": float(bd_wall_us),
                                   "note": "kernel durations from dispatch timestamps (ppo_prof_arm), means over 12 "
