@@ -1,6 +1,6 @@
 """bench.py -- env-steps/sec of the PPO rollout + GAE hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]       (N > 1 without a launcher: starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch, the bracket the reference times as
@@ -9,7 +9,8 @@ of the whole-rollout kernel (ppo_rollout_fused: per time step the dense 64-64 ta
 network on the matrix cores, Philox action sampling, the fp64 env transition with auto-reset, and, for
 truncated episodes, the bootstrap value of the terminal observation from a second network pass in the
 same kernel) --, the episode-statistics kernels of that rollout (reference :404-417, inside the
-reference's bracket too) and the GAE kernel.  Workload = BASELINE.json configs[1]: CartPole,
+reference's bracket too) and the GAE kernel (the trainer's form, ppo_gae_dense_packed, reading the two flag
+bits per element the rollout kernel leaves).  Workload = BASELINE.json configs[1]: CartPole,
 N = 65536 envs x T = 128 per GPU.  With --gpus N every rank runs that workload on its own envs
 (weak scaling; the path has no data-path collective -- envs shard by batch, and the gradient
 all-reduce belongs to the update, outside this bracket).
@@ -17,9 +18,11 @@ all-reduce belongs to the update, outside this bracket).
 Network arithmetic: `value` is measured in the library's default mode (ops.NET_AUTO): f16-split MFMA
 products (22-bit operands, f32 accumulate) when ppo_rollout_pack_params' split_diag puts the parameter
 set inside the range where that mode measures as accurate as PyTorch's f32 forward
-(tests/test_gpu_net_precision.py), exact-f32 MFMA products otherwise; the bench's freshly initialised
-policy is inside it.  The same steps with exact f32 products forced are reported beside it
-(`value_with_exact_f32_products`) -- the figure to quote against the reference's f32 arithmetic.
+(tests/test_gpu_net_precision.py), three-piece bf16 splits (PPO_NET_BF16X3: operands exact, f32-grade at
+every weight scale) otherwise; the bench's freshly initialised policy is inside it.  The same steps with
+PPO_NET_BF16X3 forced are reported beside it (`value_f32_grade`) -- the figure to quote against the
+reference's f32 arithmetic -- and with every product an exact f32 FMA (`value_with_exact_f32_products`).
+`sustained`: >= --sustained-seconds of back-to-back steps in the default mode.
 
 Clocks: after idling, this GPU needs ~40 ms of sustained work before its clocks settle, and the
 VALU-bound rollout kernel follows them (tools/rollout_phase.py).  `value` is therefore
@@ -34,7 +37,8 @@ all-reduce in the loop.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the GAE kernel (the HBM-bound kernel the north
 star sets a target for), timed with HIP events on the launch stream inside the timed region;
-`rollout_kernel` describes the step's dominant kernel.  `cpu_baseline` is the oracle's serial per-env
+`rollout_kernel` describes the step's dominant kernel, `step_breakdown_us` every kernel of a step from
+its dispatch timestamps.  `ranks_seen` / `rank_devices`: what the collectives saw.  `cpu_baseline` is the oracle's serial per-env
 Python restatement of the reference's CPU path (oracle/pyref.py, kind "port"), timed on rank 0 at N=1
 on a bounded sample, plus the restated torch-CPU GAE / loss loops at the full configs[1] shape.
 """
@@ -440,11 +444,11 @@ def main():
             "hbm_write_gbs": ro_bytes / (ro_ms * 1e-3) / 1e9,
             # VALU issue: instructions per wave and step from the committed PMC summary (SQ_INSTS_VALU / waves / T,
             # CartPole joint, 64-env waves) against one wave64 instruction per SIMD every four cycles at 2.4 GHz
-            "valu_insts_per_wave_step": (1035 if (kind == "cartpole" and N > 32768) else None),
-            "valu_issue_frac": ((1035 * waves * T / (ro_ms * 1e-3)) / (1024 * 2.4e9 / 4)
+            "valu_insts_per_wave_step": (1023 if (kind == "cartpole" and N > 32768) else None),
+            "valu_issue_frac": ((1023 * waves * T / (ro_ms * 1e-3)) / (1024 * 2.4e9 / 4)
                                 if (kind == "cartpole" and N > 32768) else None),
-            "note": "neither an HBM- nor an MFMA-bound kernel: by PMC (profiles/r02_rollout_pmc_f16_split.txt) "
-                    "the VALU is active 71 % of the wave cycles (1035 instructions per wave and step: tanh, operand "
+            "note": "neither an HBM- nor an MFMA-bound kernel: by PMC (profiles/r03_rollout_pmc_f16_split.txt) "
+                    "the VALU is active 70 % of the wave cycles (1023 instructions per wave and step: tanh, operand "
                     "splits, heads, f64 physics, Philox), the 60 f16 MFMAs per wave and step are busy 25 %; duration "
                     "from the dispatch's own start/stop timestamps (step_breakdown_us)"}
         if world == 1 and not args.no_cpu_baseline:
