@@ -55,7 +55,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: best measured float4 copy (SURVEY 8d asks for both fractions)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense BF16/FP16 MFMA
 GAE_BYTES_PER_ELEM = 12.25     # the trainer's GAE (ppo_gae_dense_packed): r, v and two flag BITS read, adv written; the
                                # end value is read only where trunc != 0 (4 B more for those cells).  The API form
@@ -414,6 +415,7 @@ def main():
                        "num_envs_per_gpu": N, "rollout_len": T, "net_mode": f"auto -> {mode_used}", "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "k_gae_words (ppo_gae_dense_packed)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes,
                          "achieved_at_api_20B_per_elem": 20 * T * N / (gae_ms * 1e-3) / 1e9,
                          "achieved_if_dense_24B_per_elem": 24 * T * N / (gae_ms * 1e-3) / 1e9,
