@@ -225,3 +225,28 @@ def test_cpu_tensors_are_staged_not_computed_on_cpu():
     adv = ppo.compute_advantages(r, v, torch.tensor([5.0, 6.0]), d, tr)  # both-flags probe, SURVEY.md 8c
     assert adv.device.type == "cpu"
     assert torch.allclose(adv.flatten(), torch.tensor([-1.2778246, -3.4639282, 4.7250700, 2.9400001]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("kind,N,T", [("cartpole", 200, 37), ("acrobot", 96, 5), ("cartpole", 64, 16), ("cartpole", 4100, 129)])
+def test_rollout_kernel_flag_words_at_ragged_lengths(kind, N, T):
+    """The flag words the whole-rollout kernel leaves (two bits per element, sixteen steps per word, the last word
+    partly filled when T is not a multiple of 16) are the packed i32 flag arrays, and the trainer's GAE on them equals
+    ppo_gae_dense on the arrays and the oracle, bit for bit; a second rollout into the same buffers too."""
+    from ppo_amd import Agent, SyncVecEnv, ops
+    from ppo_amd.envs import DeviceEnv
+    torch.manual_seed(1)
+    probe = DeviceEnv(kind)
+    agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
+    ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=3), N, T, 0, 0.0, agent, seed=3)
+    for _ in range(2):
+        ve.rollout()
+        assert ve._ev_ready and ve._flag_words.shape == ((T + 15) // 16, N)
+        d, tr = ve.done_flags, ve.trunc_flags
+        assert torch.equal(ve._flag_words, ops.pack_flag_words(d, tr))
+        want = ops.gae_dense(ve.rewards, ve.values, ve._ev_dense, d, tr, 0.99, 0.95)
+        got = ops.gae_dense_packed(ve.rewards, ve.values, ve._ev_dense, ve._flag_words, 0.99, 0.95)
+        assert torch.equal(got, want)
+        evz = torch.where(tr > 0, ve._ev_dense, torch.zeros_like(ve._ev_dense))
+        ref = cref.gae_dense(ve.rewards.cpu().numpy(), ve.values.cpu().numpy(), evz.cpu().numpy(), d.cpu().numpy(),
+                             tr.cpu().numpy(), 0.99, 0.95)
+        assert np.array_equal(got.cpu().numpy(), ref)
