@@ -324,7 +324,8 @@ size_t ppo_rollout_param_floats(int kind, int joint, int net_mode);
  *                  over the backbones): the size of the pre-activations, where a 22-bit product is
  *                  less accurate than an f32 one.
  *              ppo_amd.ops.split_ok() holds the measured thresholds ([2] <= 8.5 is the one that
- *              matters: 2x the reference's orthogonal initialisation); use PPO_NET_F32 outside them.
+ *              matters: 2x the reference's orthogonal initialisation); use PPO_NET_BF16X3 (or PPO_NET_F32)
+ *              outside them.
  */
 int ppo_rollout_pack_params(int kind, int joint, int net_mode, const float *pi_w1, const float *pi_b1,
                             const float *pi_w2, const float *pi_b2, const float *va_w1,

@@ -440,7 +440,7 @@ def rollout_param_floats(kind: int, joint, net_mode: int) -> int:
 def pack_dense_agent(agent, net_mode: int = NET_F32, out: torch.Tensor | None = None,
                      diag_out: torch.Tensor | None = None) -> torch.Tensor:
     """ppo_rollout_pack_params: the dense Agent's nn.Linear tensors -> the layout k_rollout reads, one
-    launch, no host work beyond the call.  net_mode is NET_F32 or NET_F16_SPLIT; diag_out (device
+    launch, no host work beyond the call.  net_mode is NET_F32, NET_F16_SPLIT or NET_BF16X3; diag_out (device
     f32[3]) receives split_diag, the accuracy indicators of the split mode for this parameter set."""
     lib = _lib.load()
     assert net_mode in (NET_F32, NET_F16_SPLIT, NET_BF16X3)
@@ -472,8 +472,8 @@ def pack_dense_agent(agent, net_mode: int = NET_F32, out: torch.Tensor | None = 
 
 def resolve_net_mode(agent, net_mode: int):
     """(params, mode actually used, split_ok or None) for a requested mode.  NET_AUTO packs for the
-    split kernels, reads split_diag back (one small device->host copy) and falls back to the exact-f32
-    layout when the parameter set is outside the split mode's limits."""
+    f16-split kernels, reads split_diag back (one small device->host copy) and falls back to NET_AUTO_FALLBACK
+    (the three-piece bf16 layout) when the parameter set is outside that mode's limits."""
     if net_mode != NET_AUTO:
         return pack_dense_agent(agent, net_mode), net_mode, None
     diag = torch.empty(3, dtype=torch.float32, device=agent.policy.weight.device)
