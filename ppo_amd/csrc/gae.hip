@@ -288,56 +288,6 @@ __global__ void __launch_bounds__(256) k_gae_sparse(GaeArgs a)
     }
 }
 
-// Experimental: the same kernel with the r / v / flag loads THREE blocks ahead (four stages).
-template <int VEC, int U>
-__global__ void __launch_bounds__(64) k_gae_sparse4(GaeArgs a)
-{
-    const size_t col = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
-    if (col >= (size_t)a.N) return;
-    float nv[VEC], na[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) { nv[k] = 0.0f; na[k] = 0.0f; }
-    const int nblk = a.T / U;
-    int t = a.T - 1;
-    FlagBlock<VEC, U> f0, f1, f2, f3;
-    EvBlock<VEC, U> e0, e1;
-    if (nblk > 0) load_flags<VEC, U>(f0, a, col, t);
-    if (nblk > 1) load_flags<VEC, U>(f1, a, col, t - U);
-    if (nblk > 2) load_flags<VEC, U>(f2, a, col, t - 2 * U);
-    if (nblk > 0) load_ev_sparse<VEC, U>(e0, f0, a, col, t);
-    for (int b = 0; b < nblk; ++b) {
-        if (b + 3 < nblk) load_flags<VEC, U>(f3, a, col, t - 3 * U);
-        if (b + 1 < nblk) load_ev_sparse<VEC, U>(e1, f1, a, col, t - U);
-        consume_sparse<VEC, U>(f0, e0, a, col, t, nv, na);
-        f0 = f1; f1 = f2; f2 = f3; e0 = e1;
-        t -= U;
-    }
-    for (; t >= 0; --t) {
-        FlagBlock<VEC, 1> f;
-        EvBlock<VEC, 1> e;
-        load_flags<VEC, 1>(f, a, col, t);
-        load_ev_sparse<VEC, 1>(e, f, a, col, t);
-        consume_sparse<VEC, 1>(f, e, a, col, t, nv, na);
-    }
-}
-
-template <int VEC, int U> int launch_gae_sparse4(const GaeArgs &a, hipStream_t s)
-{
-    const long threads = a.N / VEC;
-    const long grid = (threads + 63) / 64;
-    hipLaunchKernelGGL((k_gae_sparse4<VEC, U>), dim3((unsigned)grid), dim3(64), 0, s, a);
-    return ppo_launch_status();
-}
-
-// Experimental: block size forced (the default picks 64 threads when there are few columns)
-template <int VEC, int U, int BLOCK> int launch_gae_sparse_block(const GaeArgs &a, hipStream_t s)
-{
-    const long threads = a.N / VEC;
-    const long grid = (threads + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL((k_gae_sparse<VEC, U, false>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
-    return ppo_launch_status();
-}
-
 template <int VEC, int U, bool NT = false> int launch_gae_sparse(const GaeArgs &a, hipStream_t s)
 {
     const long threads = a.N / VEC;
@@ -771,7 +721,9 @@ template <int VEC, int U, bool DENSE_EV> int launch_gae(const GaeArgs &a, hipStr
 }
 
 // Variant table (tools/tune_gae.py; numbers in DESIGN.md).  0-1 stream the dense end-value
-// buffer, 2-7 fetch it only where a truncation is flagged; 6-7 use non-temporal accesses (measured
+// buffer, 2-7 fetch it only where a truncation is flagged; 6-7 use non-temporal accesses (round 2 also measured
+// four-stage, 16-row, four-column and forced-workgroup-size forms, numbered 8-14 in profiles/r02_gae_variants_*.txt:
+// none faster, removed) (measured
 // inside bench.py: <2,8> 34.0 us, <2,8,nt> 39.5, <1,8> 35.2, <1,8,nt> 33.5 -- no clear win, and the
 // <2,8> form is sensitive to how the compiler schedules its loads, so its source is left as it is).
 int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s)
@@ -785,22 +737,13 @@ int launch_gae_dense_variant(const GaeArgs &a, int variant, hipStream_t s)
     case 5: return launch_gae_sparse<2, 8>(a, s);
     case 6: return launch_gae_sparse<2, 8, true>(a, s);
     case 7: return launch_gae_sparse<1, 8, true>(a, s);
-    case 8: return launch_gae_sparse4<2, 8>(a, s);
-    case 9: return launch_gae_sparse4<2, 4>(a, s);
-    case 10: return launch_gae_sparse<4, 4>(a, s);
-    case 11: return launch_gae_sparse_block<2, 8, 128>(a, s);
-    case 12: return launch_gae_sparse_block<2, 8, 256>(a, s);
-    case 13: return launch_gae_sparse<2, 16>(a, s);
-    case 14: return launch_gae_sparse4<1, 8>(a, s);
     default: return (int)hipErrorInvalidValue;
     }
 }
 
 int variant_vec(int variant)
 {
-    if (variant == 10) return 4;
-    return (variant == 1 || variant == 4 || variant == 5 || variant == 6 || variant == 8 || variant == 9 ||
-            variant == 11 || variant == 12 || variant == 13) ? 2 : 1;
+    return (variant == 1 || variant == 4 || variant == 5 || variant == 6) ? 2 : 1;
 }
 
 }  // namespace

@@ -88,8 +88,8 @@ def test_dense_vs_oracle_all_variants(T, N):
     dev = [torch.from_numpy(x).cuda() for x in (r, v, ev, d, tr)]
     got, ret = ops.gae_dense(*dev, 0.99, 0.95, want_returns=True)
     assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(ret.cpu().numpy(), want_ret)
-    for variant in range(6):
-        vec = 2 if variant in (1, 4, 5) else 1
+    for variant in range(8):
+        vec = 2 if variant in (1, 4, 5, 6) else 1
         if N % vec:
             continue
         got = ops.gae_dense(*dev, 0.99, 0.95, variant=variant)

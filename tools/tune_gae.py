@@ -44,7 +44,7 @@ for _ in range(a.sets):
 bytes_ = 24 * T * N
 res = {}
 for variant in [int(x) for x in a.variants.split(",")]:
-    vec = 4 if variant == 10 else (2 if variant in (1, 4, 5, 6, 8, 9, 11, 12, 13) else 1)
+    vec = 2 if variant in (1, 4, 5, 6) else 1
     if N % vec:
         continue
     for i in range(3):

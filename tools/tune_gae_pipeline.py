@@ -7,7 +7,7 @@ import numpy as np
 import torch
 from ppo_amd import Agent, SyncVecEnv, ops
 from ppo_amd.envs import DeviceEnv
-variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "5,3,4,8,10,11,12,13,6,7").split(",")]
+variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "5,3,4,6,7").split(",")]
 N, T = 65536, 128
 probe = DeviceEnv("cartpole")
 agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
