@@ -348,7 +348,7 @@ def main():
     # (ppo_prof_arm: hipExtLaunchKernelGGL's events time the dispatch packet itself, like rocprofv3 --kernel-trace;
     # a torch.cuda.Event pair around a launch also times two barrier packets and reads 25-50 us high).  Outside the
     # timed region: an event pair costs ~5.7 us of the step it sits in.  A step launches, in this order: the
-    # episode statistics of the PREVIOUS rollout (3 kernels), the rollout kernel, GAE.
+    # episode statistics of the PREVIOUS rollout (2 kernels: ppo_episode_stats_incremental_ints), the rollout kernel, GAE.
     us = C.c_float()
 
     def slot_us(slot):
@@ -359,17 +359,18 @@ def main():
         hot_path_step(False)
     per_kernel = []
     bd_t0 = 0.0
+    L, NS = 4, 2                                   # launches per step, of which statistics kernels
     for k in range(16):
         if k == 4:                                 # (first four: settle)
             torch.cuda.synchronize()
             bd_t0 = time.perf_counter()
-        _lib.check(lib.ppo_prof_arm(128 + 5 * k, 5), "ppo_prof_arm")
+        _lib.check(lib.ppo_prof_arm(128 + L * k, L), "ppo_prof_arm")
         hot_path_step(False)
     _lib.check(lib.ppo_prof_arm(0, 0), "ppo_prof_arm")
     torch.cuda.synchronize()
     bd_wall_us = (time.perf_counter() - bd_t0) / 12 * 1e6     # wall time per step of the same twelve (instrumented) steps
-    per_kernel = np.array([[slot_us(128 + 5 * k + j) for j in range(5)] for k in range(4, 16)])   # (first four: settle)
-    stats_us, ro_us, gae_bd_us = per_kernel[:, :3].sum(1).mean(), per_kernel[:, 3].mean(), per_kernel[:, 4].mean()
+    per_kernel = np.array([[slot_us(128 + L * k + j) for j in range(L)] for k in range(4, 16)])   # (first four: settle)
+    stats_us, ro_us, gae_bd_us = per_kernel[:, :NS].sum(1).mean(), per_kernel[:, NS].mean(), per_kernel[:, NS + 1].mean()
     ro_ms = float(ro_us) * 1e-3
     waves = (N + 63) // 64 if N > 32768 else (N + 31) // 32          # 64- or 32-env waves (csrc/rollout.hip)
     mfma_per_wave_step = 60 if N > 32768 else 30                      # 32x32x16 f16 MFMAs, joint net
@@ -427,8 +428,8 @@ def main():
                                  "input, written by the rollout kernel just before, is served by the 256 MiB Infinity "
                                  "Cache; with HBM-cold inputs (profiles/r03_gae_packed_variants.txt) the kernel takes "
                                  "23.6 us, and `traffic` is the L2-to-fabric byte count of such a cold launch"},
-            "step_breakdown_us": {"episode_statistics_3_kernels": float(stats_us),
-                                  "episode_statistics_each": [float(x) for x in per_kernel[:, :3].mean(0)],
+            "step_breakdown_us": {"episode_statistics_2_kernels": float(stats_us),
+                                  "episode_statistics_each": [float(x) for x in per_kernel[:, :NS].mean(0)],
                                   "k_rollout": float(ro_us),
                                   "k_gae": float(gae_bd_us), "sum": float(stats_us + ro_us + gae_bd_us),
                                   "wall_per_step_of_these_steps": float(bd_wall_us),
@@ -436,7 +437,7 @@ def main():
                                           "back-to-back steps after the timed region, with the wall time per step of those "
                                           "same twelve steps (every launch carrying an event pair, ~1 us each, so they run "
                                           "a little slower than the timed region's); wall minus sum is dispatch gaps "
-                                          "between the five launches of a step"},
+                                          "between the four launches of a step"},
         }
         line["rollout_kernel"] = {
             "kernel": f"k_rollout (ppo_rollout_fused), {mode_used}", "bound": "valu-issue",

@@ -413,6 +413,21 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
                                   void *stream);
 
 /*
+ * ppo_episode_stats_incremental for rings that hold only values whose f32 pattern has its low 10 bits clear --
+ * integers of magnitude below 8192: the returns and lengths of CartPole-v1 / Acrobot-v1 (sums of +-1 rewards and
+ * step counts under TimeLimit(500), src/env_cartpole.py:7-8, src/env_acrobot.py:7-8), i.e. everything the env
+ * kernels of this library write.  The 22 key bits known after level 1 of the select are then the whole key, so
+ * the level-2 pass is not launched at all (two launches per call instead of three; an idle launch costs ~4 us
+ * between two kernels of a rollout).  Same state block, same results bit for bit; the two forms may be mixed on
+ * one state.  The promise is CHECKED, not trusted: the state counts the window's values with low bits set, and
+ * while there is one, stats5 is set to NaN (all five; the running maximum restarts with the next good call)
+ * instead of a truncated value.  What SyncVecEnv.rollout calls for the native envs (src/ppo.py:404-417).
+ */
+int ppo_episode_stats_incremental_ints(const float *ret_ring, const int *len_ring, const int *ring_cnt,
+                                       int ring, int N, double *stats5, void *state, size_t state_bytes,
+                                       void *stream);
+
+/*
  * Job-wide episode statistics when the envs are sharded over data-parallel ranks.  The reference takes its
  * percentiles over EVERY env's deques (src/ppo.py:404-417); with one env shard per GPU the same numbers come from
  * a radix select whose histograms are added up over the ranks, one all-reduce per level, and narrowed by the

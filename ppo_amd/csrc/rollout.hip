@@ -661,8 +661,10 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
             a.values[row] = value;
             a.rewards[row] = o.reward;
             rsum += o.reward;
-            a.done[row] = o.done;
-            a.trunc[row] = o.trunc;
+            // the i32 flag arrays are the API's format; the GAE that follows a rollout in the trainer reads the flag
+            // words below, so these stream past the caches too (A/B at C2, three rounds: 477.9 -> 476.0 us per step)
+            __builtin_nontemporal_store(o.done, a.done + row);
+            __builtin_nontemporal_store(o.trunc, a.trunc + row);
             flag_bits |= (uint32_t)(o.done | (o.trunc << 1)) << (2 * (t & 15));
             if ((t & 15) == 15 || t == a.T - 1) {   // sixteen steps of flags per word
                 if (a.flag_words) a.flag_words[(size_t)(t >> 4) * N + n] = flag_bits;

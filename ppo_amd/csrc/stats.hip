@@ -243,6 +243,14 @@ __device__ void sel_finalize(double *stats5, const uint32_t *prefix, int bits, u
     stats5[4] = lerp_pair(v[7], v[8], n, 0.50);
 }
 
+// ppo_episode_stats_incremental_ints: the caller promised values whose 22 leading key bits are the whole key (no
+// level-2 launch) and the rings hold one that is not -- the percentiles cannot be finished, so they say so: NaN
+// (the running maximum too; it recovers with the next good call), never a silently truncated value.
+__device__ void sel_poison(double *stats5)
+{
+    for (int k = 0; k < 5; ++k) stats5[k] = __longlong_as_double(0x7ff8000000000000ll);
+}
+
 // rank of target t among n values: (lower, upper) neighbours of p5, p50, p95 of the returns, their
 // maximum, (lower, upper) of the median length
 __device__ unsigned long long sel_target_rank(int t, unsigned long long n)
@@ -258,7 +266,7 @@ __device__ unsigned long long sel_target_rank(int t, unsigned long long n)
 // no episode has finished, like the reference's attributes (src/ppo.py:250-254, :408-417).
 // INCR (incremental form): hist0 and hist1 persist between calls and are never cleared here, and
 // whether level 2 is needed comes from the state's running count `nz` instead of this pass.
-template <int LEVEL, bool INCR> __device__ void sel_narrow(const SelWs &w, const uint32_t *hist, double *stats5)
+template <int LEVEL, bool INCR> __device__ void sel_narrow(const SelWs &w, const uint32_t *hist, double *stats5, int ints_only)
 {
     __shared__ unsigned long long s_rank[SEL_T];
     __shared__ uint32_t s_prefix[SEL_T];
@@ -320,6 +328,11 @@ template <int LEVEL, bool INCR> __device__ void sel_narrow(const SelWs &w, const
     if (LEVEL == 0) __hip_atomic_store(&st->low_bits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (LEVEL == 1) st->skip2 = last ? 1 : 0;
     if (LEVEL == 1 && INCR) st->skip1 = 1;                   // the tracked histograms are complete again
+    if (LEVEL == 1 && INCR && !last && ints_only) {          // the caller launches no level 2 (see sel_poison)
+        st->skip2 = 1;
+        sel_poison(stats5);
+        return;
+    }
     if (!last) sel_setup_next(st, s_prefix, s_rank, n, false);
     else sel_finalize(stats5, s_prefix, LEVEL == 1 ? 22 : 32, n);
 }
@@ -406,7 +419,7 @@ __device__ __forceinline__ void sel_walk(const float *ret_ring, const int *len_r
 
 template <int LEVEL, bool INCR>
 __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, const int *len_ring, const int *ring_cnt,
-                                                      int ring, int N, SelWs w, double *stats5)
+                                                      int ring, int N, SelWs w, double *stats5, int ints_only)
 {
     constexpr int NH = LEVEL == 0 ? 2 : SEL_T, NB = LEVEL == 0 ? SEL_B0 : SEL_B1;
     __shared__ uint32_t h[LEVEL == 0 ? SEL_H0_LDS : NH * NB];   // level 0: room for the padded copy the narrowing reads
@@ -457,7 +470,7 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, co
     __syncthreads();                                         // (level 0: every thread is done with the unpadded layout)
     f.template store<LEVEL == 0>(h);
     __syncthreads();
-    sel_narrow<LEVEL, INCR>(w, h, stats5);
+    sel_narrow<LEVEL, INCR>(w, h, stats5, ints_only);
 }
 
 // Histogram pass alone, for a selection that is narrowed OUTSIDE this library: data-parallel ranks add up their
@@ -491,9 +504,10 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_hist_level(const float *ret_r
 
 template <int LEVEL, bool INCR = false>
 int sel_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N, const SelWs &w,
-              double *stats5, unsigned blocks, hipStream_t s)
+              double *stats5, unsigned blocks, hipStream_t s, int ints_only = 0)
 {
-    PPO_LAUNCH((k_sel<LEVEL, INCR>), dim3(blocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5);
+    PPO_LAUNCH((k_sel<LEVEL, INCR>), dim3(blocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5,
+               ints_only);
     return ppo_launch_status();
 }
 
@@ -541,7 +555,7 @@ constexpr int INCR_ENVS = 256;           // envs a workgroup takes per pass (the
 
 __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr(const float *__restrict__ ret_ring, const int *__restrict__ len_ring,
                                                            const int *__restrict__ ring_cnt, int ring, int N, SelWs w,
-                                                           IncrBufs ib, double *stats5)
+                                                           IncrBufs ib, double *stats5, int ints_only)
 {
     __shared__ uint32_t h0[SEL_H0_LDS];                        // deltas in the first 2 * SEL_B0 words; later the padded copy
     __shared__ uint32_t h1[SEL_T * SEL_B1];
@@ -727,6 +741,10 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr(const float *__restr
         st->n = n;
         st->skip2 = 1;
         sel_finalize(stats5, s_prefix, 22, n);
+    } else if (ints_only) {                                    // ... and the caller launches no level 2 (see sel_poison)
+        st->n = n;
+        st->skip2 = 1;
+        sel_poison(stats5);
     } else {                                                   // values with low float bits set: level 2 over the rings
         sel_setup_next(st, s_prefix, s_rank, n, false);
         st->skip2 = 0;
@@ -788,8 +806,8 @@ size_t ppo_episode_stats_state_bytes(int N, int ring)
     return incr_state_bytes(N, ring);
 }
 
-int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
-                                  double *stats5, void *state, size_t state_bytes, void *stream)
+static int episode_stats_incremental(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
+                                     double *stats5, void *state, size_t state_bytes, void *stream, int ints_only)
 {
     PPO_REQUIRE(N >= 0 && ring > 0 && (unsigned long long)N * (unsigned long long)ring < 0xFFFFFFFFull);
     PPO_REQUIRE(stats5 && ppo_aligned(stats5, 8));
@@ -805,7 +823,7 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
     size_t iblocks = ((size_t)N + INCR_ENVS - 1) / INCR_ENVS;
     if (iblocks > 256) iblocks = 256;
     PPO_LAUNCH(k_sel_incr, dim3((unsigned)iblocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, w,
-                       ib, stats5);
+                       ib, stats5, ints_only);
     int rc = ppo_launch_status();
     if (rc) return rc;
     // the two full passes: return at once unless a wanted prefix is untracked (level 1) or values are
@@ -815,9 +833,21 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
     size_t blocks = ((size_t)N * ring + SEL_HBLOCK * SEL_U - 1) / (SEL_HBLOCK * SEL_U);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    rc = sel_level<1, true>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
-    if (rc) return rc;
+    rc = sel_level<1, true>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s, ints_only);
+    if (rc || ints_only) return rc;                  // (ints_only: level 1 always ends the selection, or poisons it)
     return sel_level<2, true>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
+}
+
+int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
+                                  double *stats5, void *state, size_t state_bytes, void *stream)
+{
+    return episode_stats_incremental(ret_ring, len_ring, ring_cnt, ring, N, stats5, state, state_bytes, stream, 0);
+}
+
+int ppo_episode_stats_incremental_ints(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
+                                       double *stats5, void *state, size_t state_bytes, void *stream)
+{
+    return episode_stats_incremental(ret_ring, len_ring, ring_cnt, ring, N, stats5, state, state_bytes, stream, 1);
 }
 
 }  // extern "C"

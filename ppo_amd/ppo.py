@@ -462,7 +462,7 @@ class SyncVecEnv:
         """reference src/ppo.py:407-417 on the device rings, without a host round trip: running max,
         5/50/95 percentiles (np.percentile 'linear') of the last <=100 returns of every env, median
         length -- a radix select, three launches on the rollout's stream.  `incremental` (what a rollout
-        uses): ppo_episode_stats_incremental, which visits only the ring slots written since its last
+        uses): ppo_episode_stats_incremental(_ints), which visits only the ring slots written since its last
         call and needs the rings to have changed by appended episodes only (the env kernels);
         otherwise ppo_episode_stats, a full scan of whatever the rings hold.  Same results.
         The result stays a device tensor until one of the statistics attributes is read."""
@@ -476,9 +476,12 @@ class SyncVecEnv:
             if self._stats_state is None:
                 self._stats_state = torch.zeros(lib.ppo_episode_stats_state_bytes(b.num_envs, b.ring), dtype=torch.uint8,
                                                 device=b.device)
-            ops._lib.check(lib.ppo_episode_stats_incremental(*rings, self._stats5.data_ptr(), self._stats_state.data_ptr(),
-                                                             self._stats_state.numel(), ops._stream()),
-                           "ppo_episode_stats_incremental")
+            # the rings are written by the env kernels only: returns are sums of +-1 rewards, lengths step counts
+            # under TimeLimit(500) -- small integers, for which the select ends after level 1 (no third launch;
+            # a value that is not one would turn the statistics into NaN, not into a wrong number)
+            ops._lib.check(lib.ppo_episode_stats_incremental_ints(*rings, self._stats5.data_ptr(), self._stats_state.data_ptr(),
+                                                                  self._stats_state.numel(), ops._stream()),
+                           "ppo_episode_stats_incremental_ints")
         else:
             ops._lib.check(lib.ppo_episode_stats(*rings, self._stats5.data_ptr(), self._stats_ws.data_ptr(),
                                                  self._stats_ws.numel(), ops._stream()), "ppo_episode_stats")

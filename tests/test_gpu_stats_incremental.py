@@ -90,12 +90,17 @@ def test_incremental_statistics_follow_the_deques(case):
     ws = torch.zeros(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device="cuda")
     s_inc = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
     s_full = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
+    # the two-launch form for small integers (what a rollout calls), on a state block of its own
+    state_i = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    s_int = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
     running_max = None
     fast_calls = 0
 
     def call():
         assert lib.ppo_episode_stats_incremental(d_ret.data_ptr(), d_len.data_ptr(), d_cnt.data_ptr(), ring, N,
                                                  s_inc.data_ptr(), state.data_ptr(), state.numel(), None) == 0
+        assert lib.ppo_episode_stats_incremental_ints(d_ret.data_ptr(), d_len.data_ptr(), d_cnt.data_ptr(), ring, N,
+                                                      s_int.data_ptr(), state_i.data_ptr(), state_i.numel(), None) == 0
         assert lib.ppo_episode_stats(d_ret.data_ptr(), d_len.data_ptr(), d_cnt.data_ptr(), ring, N,
                                      s_full.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
         torch.cuda.synchronize()
@@ -124,6 +129,12 @@ def test_incremental_statistics_follow_the_deques(case):
         assert (nz == 0) == (case != "floats")
         assert skip2 == (1 if case != "floats" else 0)
         fast_calls += int(skip1 == 1 and skip2 == 1)
+        ints = s_int.cpu().numpy()
+        if case != "floats":                             # integer-valued: the same numbers without the third launch
+            assert np.array_equal(ints, got), (case, c, ints, got)
+        else:                                            # promise broken: NaN, never a truncated value
+            assert (_flags(state_i)[2] != 0) and np.isnan(ints).all(), (case, c, ints)
+        assert _flags(state_i)[1] == 1                   # level 2 is never asked for
     if case in ("cartpole_ints", "acrobot_negative", "constant"):
         assert fast_calls >= calls - 2, fast_calls       # steady distributions: no full pass after the first calls
     # the rings rewritten behind the state's back (a restored checkpoint): zero the state, start over
@@ -131,10 +142,12 @@ def test_incremental_statistics_follow_the_deques(case):
     h2.append(rng.integers(0, 2 * ring, N).astype(np.int32), lambda k: draw(rng, k, 1),
               lambda k: rng.integers(1, 501, k).astype(np.int32))
     d_ret.copy_(torch.from_numpy(h2.ret)); d_len.copy_(torch.from_numpy(h2.len)); d_cnt.copy_(torch.from_numpy(h2.cnt))
-    state.zero_()
-    s_inc.fill_(float("nan")); s_full.fill_(float("nan"))
+    state.zero_(); state_i.zero_()
+    s_inc.fill_(float("nan")); s_full.fill_(float("nan")); s_int.fill_(float("nan"))
     got, full = call()
     assert np.array_equal(got, full)
+    if case != "floats":
+        assert np.array_equal(s_int.cpu().numpy(), got)
     want = _want(h2)
     assert got[0] == want[0] and np.allclose(got[1:4], want[1:4], rtol=1e-12, atol=0.0) and got[4] == want[4]
 
@@ -169,3 +182,5 @@ def test_incremental_statistics_at_bench_scale_through_rollouts():
     want = np.percentile(r.cpu().numpy().astype(np.float64), [5.0, 50.0, 95.0])
     assert np.allclose(s_inc.cpu().numpy()[1:4], want, rtol=1e-12, atol=0.0)
     assert all(fast[2:]), fast
+    ve._flush_stats()                                    # the rollouts' own statistics: the two-launch integer form
+    assert torch.equal(ve._stats5, s_inc), (ve._stats5, s_inc)
