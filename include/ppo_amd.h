@@ -37,8 +37,9 @@ extern "C" {
 
 /* 2: the sampling stream of ppo_categorical_sample / ppo_rollout_fused draws one Philox block per FOUR policy
  *    steps (counter = step / 4, word = step % 4; version 1 drew one block per step), so a run resumed across the
- *    two versions samples different actions; PPO_NET_BF16X3 added; private hooks changed. */
-#define PPO_AMD_ABI_VERSION 2
+ *    two versions samples different actions; PPO_NET_BF16X3 added; private hooks changed.
+ * 3: ppo_episode_stats_incremental_ints added; nothing else changed. */
+#define PPO_AMD_ABI_VERSION 3
 
 #define PPO_ENV_CARTPOLE 0 /* CartPole-v1: obs_dim 4, actions {0,1}   */
 #define PPO_ENV_ACROBOT 1  /* Acrobot-v1:  obs_dim 6, actions {0,1,2} */
