@@ -73,6 +73,10 @@ def _gloo_on_device(t: torch.Tensor) -> bool:
     return t.is_cuda and td.get_backend() == "gloo"
 
 
+def _host_under_rccl(t: torch.Tensor) -> bool:
+    return (not t.is_cuda) and td.get_backend() == "nccl"
+
+
 def _raw_all_reduce(t: torch.Tensor, op):
     """RCCL collectives are stream-ordered kernels.  gloo (only used to rehearse several ranks on ONE GPU)
     is given host tensors: its device-tensor path stages through the host on streams of its own, and with
@@ -82,6 +86,11 @@ def _raw_all_reduce(t: torch.Tensor, op):
         h = t.cpu()                       # synchronous device -> host copy: the stream is drained
         td.all_reduce(h, op=op)
         t.copy_(h)
+        return
+    if _host_under_rccl(t):               # RCCL moves device memory only (host-stepped envs hand over numpy-backed tensors)
+        d = t.cuda()
+        td.all_reduce(d, op=op)
+        t.copy_(d)
         return
     td.all_reduce(t, op=op)
 
@@ -118,6 +127,10 @@ def _collective(t: torch.Tensor, op, tag: str, broadcast_src: int | None = None)
         h = t.cpu()                       # see _raw_all_reduce
         td.broadcast(h, broadcast_src)
         t.copy_(h)
+    elif _host_under_rccl(t):
+        d = t.cuda()
+        td.broadcast(d, broadcast_src)
+        t.copy_(d)
     else:
         td.broadcast(t, broadcast_src)
 
