@@ -59,8 +59,10 @@ __device__ __forceinline__ double div_by_total_mass(double x)
 struct CartPole {
     static constexpr int OBS = 4;
     struct Aux {};                                 // nothing derived from the state is worth carrying
-    __device__ static void prime(const double (&)[4], Aux &) {}
+    static constexpr bool PAIR_TRIG = false;       // (see Acrobot)
+    template <bool PAIR = false> __device__ static void prime(const double (&)[4], Aux &) {}
 
+    template <bool PAIR = false>
     __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &)
     {
 #pragma unroll
@@ -71,6 +73,7 @@ struct CartPole {
     }
 
     // returns terminated; reward is always 1.0
+    template <bool PAIR = false>
     __device__ static bool step(double (&s)[4], Aux &, int action, float (&obs)[6], float &reward)
     {
         constexpr double gravity = 9.8, masscart = 1.0, masspole = 0.1;
@@ -123,31 +126,49 @@ struct Acrobot {
     // step's first RK4 stage needs: they travel with the state (Aux) in the kernels that keep an env
     // in registers across steps -- 8 calls per step; a kernel that loads the state primes them with
     // the same two calls, so both forms compute the same numbers.
+    //
+    // PAIR (the whole-rollout kernel's 32-env waves, small batches): lanes l and l + 32 of such a wave carry the SAME
+    // env -- the matrix-core tile is 32 envs wide, the upper half-wave only holds the other halves of its operands --
+    // so the two lanes split every pair of calls: the lower lane reduces theta1, the upper one theta2, and they
+    // exchange the results.  One sincos per pair instead of two with all 64 lanes busy, 4 instead of 8 per step; the
+    // function values are the same whichever lane computes them, so results are bit-identical to the unpaired form.
+    // Every call site is reached by both lanes of a pair or by neither (they hold identical state).
     struct Trig { double s1, c1, s2, c2; };
     using Aux = Trig;
-    __device__ static void prime(const double (&s)[4], Aux &aux) { aux = trig_of(s[0], s[1]); }
-    __device__ static Trig trig_of(double theta1, double theta2)
+    static constexpr bool PAIR_TRIG = true;
+    template <bool PAIR = false> __device__ static void prime(const double (&s)[4], Aux &aux) { aux = trig_of<PAIR>(s[0], s[1]); }
+    template <bool PAIR = false> __device__ static Trig trig_of(double theta1, double theta2)
     {
         Trig t;
-        sincos(theta1, &t.s1, &t.c1);
-        sincos(theta2, &t.s2, &t.c2);
+        if constexpr (!PAIR) {
+            sincos(theta1, &t.s1, &t.c1);
+            sincos(theta2, &t.s2, &t.c2);
+        } else {
+            const bool upper = (threadIdx.x & 32u) != 0u;
+            double sn, cs;
+            sincos(upper ? theta2 : theta1, &sn, &cs);
+            const double so = __shfl_xor(sn, 32, 64), co = __shfl_xor(cs, 32, 64);   // the partner lane's angle
+            t.s1 = upper ? so : sn; t.c1 = upper ? co : cs;
+            t.s2 = upper ? sn : so; t.c2 = upper ? cs : co;
+        }
         return t;
     }
 
-    __device__ static Trig write_obs(const double (&s)[4], float (&obs)[6])
+    template <bool PAIR = false> __device__ static Trig write_obs(const double (&s)[4], float (&obs)[6])
     {
-        const Trig t = trig_of(s[0], s[1]);
+        const Trig t = trig_of<PAIR>(s[0], s[1]);
         obs[0] = (float)t.c1; obs[1] = (float)t.s1;
         obs[2] = (float)t.c2; obs[3] = (float)t.s2;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
         return t;
     }
 
+    template <bool PAIR = false>
     __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &aux)
     {
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] = (double)(float)(-0.1 + (0.1 - -0.1) * u[k]);  // .astype(float32)
-        aux = write_obs(s, obs);
+        aux = write_obs<PAIR>(s, obs);
     }
 
     // 1 / d for d in [0.5, 5] (the two denominators of dsdt: d1 = 3.5 + cos(theta2) and
@@ -196,6 +217,7 @@ struct Acrobot {
         return x;
     }
 
+    template <bool PAIR = false>
     __device__ static bool step(double (&s)[4], Aux &aux, int action, float (&obs)[6], float &reward)
     {
         const double dt = 0.2 - 0;
@@ -205,13 +227,13 @@ struct Acrobot {
         dsdt(s, aux, torque, k1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k1[i];
-        dsdt(y, trig_of(y[0], y[1]), torque, k2);
+        dsdt(y, trig_of<PAIR>(y[0], y[1]), torque, k2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k2[i];
-        dsdt(y, trig_of(y[0], y[1]), torque, k3);
+        dsdt(y, trig_of<PAIR>(y[0], y[1]), torque, k3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = s[i] + dt * k3[i];
-        dsdt(y, trig_of(y[0], y[1]), torque, k4);
+        dsdt(y, trig_of<PAIR>(y[0], y[1]), torque, k4);
         double ns[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) ns[i] = s[i] + dt / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
@@ -221,7 +243,7 @@ struct Acrobot {
         ns[3] = fmin(fmax(ns[3], -9 * PI), 9 * PI);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = ns[i];
-        const Trig t = aux = write_obs(s, obs);
+        const Trig t = aux = write_obs<PAIR>(s, obs);
         const bool terminated = terminal(s, t);
         reward = terminated ? 0.0f : -1.0f;
         return terminated;
@@ -324,11 +346,13 @@ struct ResetAhead {
 
 // One transition of env n.  Follows gymnasium env.step -> TimeLimit -> RecordEpisodeStatistics and
 // the actor loop of the reference's rollout (src/ppo.py:342-388).
-template <class Env, bool DRAWS = true>
+// PAIR: the caller runs this for BOTH lanes that carry env n in a 32-env wave (Acrobot::trig_of); `owner` is false in
+// the lane that only helps -- it keeps its copy of the env in step but writes nothing to memory.
+template <class Env, bool DRAWS = true, bool PAIR = false>
 __device__ __forceinline__ void env_transition(EnvRegs &e, typename Env::Aux &aux, int action, const EnvArgs &a, size_t n, int is_last,
-                                               StepOut &o, ResetAhead *ahead = nullptr)
+                                               StepOut &o, ResetAhead *ahead = nullptr, bool owner = true)
 {
-    const bool terminated = Env::step(e.s, aux, action, o.obs, o.reward);
+    const bool terminated = Env::template step<PAIR>(e.s, aux, action, o.obs, o.reward);
     e.elapsed += 1;                                          // TimeLimit.step
     const bool truncated = e.elapsed >= MAX_EPISODE_STEPS;
     o.done = terminated ? 1 : 0;
@@ -338,15 +362,15 @@ __device__ __forceinline__ void env_transition(EnvRegs &e, typename Env::Aux &au
     e.ep_len += 1;
     const bool ended = terminated || truncated;
     if (ended) {
-        if (a.ret_ring) {
+        if (a.ret_ring && (!PAIR || owner)) {
             // counters live in registers: a load here would make the wave wait for every store
             // it has in flight (vmcnt counts both), once per step in practice since some env of
             // the 64 ends an episode almost every step
             const size_t slot = n * (size_t)a.ring + (size_t)(e.ring_cnt % a.ring);
             a.ret_ring[slot] = e.ep_ret;
             a.len_ring[slot] = e.ep_len;
-            e.ring_cnt += 1;
         }
+        if (a.ret_ring) e.ring_cnt += 1;
         e.ep_ret = 0.0f;
         e.ep_len = 0;
     }
@@ -366,12 +390,12 @@ __device__ __forceinline__ void env_transition(EnvRegs &e, typename Env::Aux &au
         for (int k = 0; k < 6; ++k) o.term[k] = o.obs[k];
         if (can_reset) {
             if (ahead) {
-                Env::reset(e.s, ahead->u, o.obs, aux);
+                Env::template reset<PAIR>(e.s, ahead->u, o.obs, aux);
                 ahead->have = false;
             } else {
                 double u[4];
                 draw_reset<DRAWS>(a, n, e.episode, u);
-                Env::reset(e.s, u, o.obs, aux);
+                Env::template reset<PAIR>(e.s, u, o.obs, aux);
             }
             e.episode += 1;
             e.elapsed = 0;

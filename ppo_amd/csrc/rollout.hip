@@ -563,6 +563,10 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     static_assert(OBS % 2 == 0 && A <= 3, "fragment layout assumes an even input width and <= 3 actions");
 
     constexpr int WE = Net::WAVE_ENVS;             // envs per wave: 64, or 32 in lanes 0-31
+    // 32-env waves: lane l + 32 carries a copy of lane l's env anyway (MFMA needs all 64 lanes); for an env whose
+    // transition is dominated by pairs of trigonometric reductions (Acrobot) it takes one of each pair
+    // (env_core.h: Acrobot::trig_of<PAIR>) instead of idling through the physics
+    constexpr bool PAIR = WE == 32 && Env::PAIR_TRIG;
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * ROLLOUT_BLOCK + threadIdx.x) >> 6;
     const size_t n = wave * WE + (WE == 64 ? lane : (lane & 31));
@@ -578,7 +582,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     EnvRegs e;
     load_env(e, a.env, nn);
     typename Env::Aux aux;                         // what the env derives from its state and carries along with it
-    Env::prime(e.s, aux);
+    Env::template prime<PAIR>(e.s, aux);
     ResetAhead ahead;
     float obs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -642,8 +646,15 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
             action = lg[0] > lg[1]; logp = lg[0];
         }
 
+        if constexpr (PAIR) {                      // both lanes of a pair step their copy of the env, with ITS action
+            action = __shfl(action, lane & 31, 64);
+            if (!(ABLATE(a) & 2))
+                env_transition<Env, DRAWS, true>(e, aux, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead, live);
+        }
         if (live) {
-            if (!(ABLATE(a) & 2)) {
+            if (PAIR && !(ABLATE(a) & 2)) {
+                // (stepped above)
+            } else if (!(ABLATE(a) & 2)) {
                 env_transition<Env, DRAWS>(e, aux, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead);
             } else {
 #pragma unroll
