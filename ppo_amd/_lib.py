@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libppo_amd.so")
+LIB_PATH = os.environ.get("PPO_AMD_LIB") or os.path.join(_HERE, "libppo_amd.so")   # (PPO_AMD_LIB: A/B of two builds, development)
 
 ABI_VERSION = 3   # include/ppo_amd.h: PPO_AMD_ABI_VERSION
 

@@ -246,13 +246,10 @@ __device__ __forceinline__ void consume_sparse(const FlagBlock<VEC, U> &b, const
             fset<VEC>(rout, k, adv + v);
         }
         const size_t o = (size_t)(t_top - u) * (size_t)a.N + col;
-        if constexpr (NT) {
-            st_stream<true>(reinterpret_cast<F *>(a.adv + o), out);
-            if (a.ret) st_stream<true>(reinterpret_cast<F *>(a.ret + o), rout);
-        } else {
-            *reinterpret_cast<F *>(a.adv + o) = out;
-            if (a.ret) *reinterpret_cast<F *>(a.ret + o) = rout;
-        }
+        // non-temporal stores in every form (round 3: 33.3 -> 32.3 us cold at [128, 65536], 127 -> 118 us at
+        // [128, 262144]); NT selects non-temporal LOADS on top, which never paid
+        st_stream<true>(reinterpret_cast<F *>(a.adv + o), out);
+        if (a.ret) st_stream<true>(reinterpret_cast<F *>(a.ret + o), rout);
     }
 }
 
@@ -452,9 +449,10 @@ template <int VEC> __device__ __forceinline__ typename VecT<VEC>::F buf_ld(BufRs
 template <int VEC> __device__ __forceinline__ void buf_st(BufRsrc rs, uint32_t voff, uint32_t soff, const typename VecT<VEC>::F &x)
 {
     const auto raw = __builtin_bit_cast(typename RawT<4 * VEC>::T, x);
-    if constexpr (VEC == 1) __builtin_amdgcn_raw_buffer_store_b32(raw, rs, voff, soff, 0);
-    else if constexpr (VEC == 2) __builtin_amdgcn_raw_buffer_store_b64(raw, rs, voff, soff, 0);
-    else __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff, soff, 0);
+    constexpr int AUX = 2;                         // nt: advantages / returns are written once and read much later
+    if constexpr (VEC == 1) __builtin_amdgcn_raw_buffer_store_b32(raw, rs, voff, soff, AUX);
+    else if constexpr (VEC == 2) __builtin_amdgcn_raw_buffer_store_b64(raw, rs, voff, soff, AUX);
+    else __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff, soff, AUX);
 }
 
 // Four waves per 64 * VEC columns, WPW flag words (16 * WPW rows) per wave and pass; see the head of this section.
