@@ -426,8 +426,8 @@ def main():
                                  "achieved_* fields price this launch's duration at those counts (work done per second "
                                  "in the reference's terms, not bytes moved).  Timed inside the pipeline: part of the "
                                  "input, written by the rollout kernel just before, is served by the 256 MiB Infinity "
-                                 "Cache; with HBM-cold inputs (profiles/r03_gae_packed_variants.txt) the kernel takes "
-                                 "23.6 us, and `traffic` is the L2-to-fabric byte count of such a cold launch"},
+                                 "Cache; with HBM-cold inputs (profiles/r03_gae_nt_store_ab.txt) the kernel takes "
+                                 "21.2 us, and `traffic` is the L2-to-fabric byte count of such a cold launch"},
             "step_breakdown_us": {"episode_statistics_2_kernels": float(stats_us),
                                   "episode_statistics_each": [float(x) for x in per_kernel[:, :NS].mean(0)],
                                   "k_rollout": float(ro_us),
