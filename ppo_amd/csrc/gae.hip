@@ -296,6 +296,105 @@ template <int VEC, int U, bool NT = false> int launch_gae_sparse(const GaeArgs &
 }
 
 // ---------------------------------------------------------------------------------------
+// Ragged form (ppo_gae_ragged: the reference's own signature, end_values[E] indexed through a running
+// per-column index, src/ppo.py:468-480) on the three-stage pipeline of k_gae_sparse.  The index a row
+// gathers with depends only on the FLAGS of the rows after it in time, so the gathers of block b + 1 are
+// issued, per lane and only where trunc != 0, as soon as that block's flags have landed -- one block ahead
+// of their use, beside the loads of block b + 2 -- instead of inside the dependent chain (round 1-2:
+// k_gae<1, 8, false>, a load in the middle of every truncated step, which on this ISA also waits for every
+// prefetch issued before it: 43 us at C2 against 32 for the dense form).  Same index arithmetic, same
+// wrap-around of negative indices, same error flag.
+template <int U> struct RagEv {
+    float ev[U];
+    int bad;              // a truncated row's index fell outside [-E, E): torch would raise IndexError
+};
+
+template <int U>
+__device__ __forceinline__ long load_ev_ragged(RagEv<U> &e, const FlagBlock<1, U> &b, const GaeArgs &a, long idx)
+{
+    int any = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) any |= b.tr[u];
+    e.bad = 0;
+    if (any) {            // one branch per block; only lanes that saw a truncation walk their rows
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            e.ev[u] = 0.0f;
+            if (b.tr[u]) {
+                const long j = idx < 0 ? idx + a.E : idx;            // negative indices wrap (:478)
+                if (j >= 0 && j < a.E) e.ev[u] = a.ev[j];
+                else e.bad = 1;
+            }
+            idx -= (long)(b.d[u] + b.tr[u]);                          // :480
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            e.ev[u] = 0.0f;
+            idx -= (long)b.d[u];
+        }
+    }
+    return idx;
+}
+
+template <int U>
+__device__ __forceinline__ void consume_ragged(const FlagBlock<1, U> &b, const RagEv<U> &e, const GaeArgs &a,
+                                               size_t col, int t_top, float &nv, float &na)
+{
+    if (e.bad && a.err) *a.err = 1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float ev = b.tr[u] ? e.ev[u] : 0.0f;
+        const float adv = gae_step(b.r[u], b.v[u], b.d[u], b.tr[u], ev, a.g, a.gl, nv, na);
+        const size_t o = (size_t)(t_top - u) * (size_t)a.N + col;
+        st_stream<true>(a.adv + o, adv);
+        if (a.ret) st_stream<true>(a.ret + o, adv + b.v[u]);
+    }
+}
+
+template <int U>
+__global__ void __launch_bounds__(256) k_gae_ragged(GaeArgs a)
+{
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= (size_t)a.N) return;
+    float nv = 0.0f, na = 0.0f;                               // :470-471
+    long idx = a.idx0[col];                                   // :469
+    const int nblk = a.T / U;
+    int t = a.T - 1;
+    FlagBlock<1, U> f0, f1, f2;   // blocks b, b+1, b+2
+    RagEv<U> e0, e1;              // end values of blocks b, b+1
+    long idx_next = idx;          // index at the top row of block b+1
+    if (nblk > 0) load_flags<1, U>(f0, a, col, t);
+    if (nblk > 1) load_flags<1, U>(f1, a, col, t - U);
+    if (nblk > 0) idx_next = load_ev_ragged<U>(e0, f0, a, idx);
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 2 < nblk) load_flags<1, U>(f2, a, col, t - 2 * U);
+        long idx_after = idx_next;
+        if (b + 1 < nblk) idx_after = load_ev_ragged<U>(e1, f1, a, idx_next);
+        consume_ragged<U>(f0, e0, a, col, t, nv, na);
+        f0 = f1; f1 = f2; e0 = e1;
+        idx_next = idx_after;
+        t -= U;
+    }
+    for (; t >= 0; --t) {                                     // T % U leftover rows
+        FlagBlock<1, 1> f;
+        RagEv<1> e;
+        load_flags<1, 1>(f, a, col, t);
+        idx_next = load_ev_ragged<1>(e, f, a, idx_next);
+        consume_ragged<1>(f, e, a, col, t, nv, na);
+    }
+}
+
+template <int U> int launch_gae_ragged(const GaeArgs &a, hipStream_t s)
+{
+    const long waves = ((long)a.N + 63) / 64;
+    const int block = waves <= 2048 ? 64 : 256;  // few columns: spread the waves over all CUs
+    const long grid = ((long)a.N + block - 1) / block;
+    PPO_LAUNCH((k_gae_ragged<U>), dim3((unsigned)grid), dim3(block), s, a);
+    return ppo_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
 // Packed-flag forms.  The whole-rollout kernel also leaves the two flags of every element as TWO BITS next to the
 // i32 [T,N] buffers of the API: flag_words [ceil(T/16), N] u32, bits 2k / 2k+1 of word q of column n = done / trunc
 // of row 16 q + k.  The trainer's GAE reads those words instead of the two i32 arrays: r 4 + v 4 + 0.25 read, adv 4
@@ -971,7 +1070,7 @@ int ppo_gae_ragged(const float *rewards, const float *values, const float *end_v
     if (rc) return rc;
     GaeArgs a{rewards, values, end_values, done, trunc, nullptr, adv, nullptr, idx0, E, err_flag,
               (float)gamma, (float)(gamma * lam), T, N};
-    return launch_gae<1, 8, false>(a, s);
+    return launch_gae_ragged<8>(a, s);
 }
 
 }  // extern "C"
