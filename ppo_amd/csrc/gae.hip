@@ -39,8 +39,10 @@ template <> __device__ __forceinline__ void fset<1>(float &v, int, float x) { v 
 template <> __device__ __forceinline__ void fset<2>(float2 &v, int k, float x) { if (k == 0) v.x = x; else v.y = x; }
 template <> __device__ __forceinline__ void fset<4>(float4 &v, int k, float x) { if (k == 0) v.x = x; else if (k == 1) v.y = x; else if (k == 2) v.z = x; else v.w = x; }
 
+// (DENSE_EV is always true since round 3: the ragged form has a kernel of its own, k_gae_ragged)
 template <int VEC, int U, bool DENSE_EV> struct RowBlock {
-    typename VecT<VEC>::F r[U], v[U], ev[DENSE_EV ? U : 1];
+    static_assert(DENSE_EV, "ragged end values: k_gae_ragged");
+    typename VecT<VEC>::F r[U], v[U], ev[U];
     typename VecT<VEC>::I d[U], tr[U];
 };
 
@@ -68,7 +70,7 @@ __device__ __forceinline__ void load_block(RowBlock<VEC, U, DENSE_EV> &b, const 
         b.v[u] = *reinterpret_cast<const F *>(a.v + o);
         b.d[u] = *reinterpret_cast<const I *>(a.done + o);
         b.tr[u] = *reinterpret_cast<const I *>(a.trunc + o);
-        if (DENSE_EV) b.ev[u] = *reinterpret_cast<const F *>(a.ev + o);
+        b.ev[u] = *reinterpret_cast<const F *>(a.ev + o);
     }
 }
 
@@ -89,7 +91,7 @@ __device__ __forceinline__ float gae_step(float r, float v, int d, int tr, float
 
 template <int VEC, int U, bool DENSE_EV>
 __device__ __forceinline__ void consume_block(const RowBlock<VEC, U, DENSE_EV> &b, const GaeArgs &a, size_t col,
-                                              int t_top, float (&nv)[VEC], float (&na)[VEC], long (&idx)[VEC])
+                                              int t_top, float (&nv)[VEC], float (&na)[VEC])
 {
     using F = typename VecT<VEC>::F;
 #pragma unroll
@@ -98,17 +100,7 @@ __device__ __forceinline__ void consume_block(const RowBlock<VEC, U, DENSE_EV> &
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const int d = iget<VEC>(b.d[u], k), tr = iget<VEC>(b.tr[u], k);
-            float ev = 0.0f;
-            if (DENSE_EV) {
-                ev = tr ? fget<VEC>(b.ev[u], k) : 0.0f;  // buffer is only defined where flagged
-            } else {
-                if (tr) {                                 // rare, data-dependent gather (:478)
-                    long j = idx[k] < 0 ? idx[k] + a.E : idx[k];
-                    if (j >= 0 && j < a.E) ev = a.ev[j];
-                    else if (a.err) *a.err = 1;           // torch would raise IndexError
-                }
-                idx[k] -= (long)(d + tr);                 // :480
-            }
+            const float ev = tr ? fget<VEC>(b.ev[u], k) : 0.0f;  // buffer is only defined where flagged
             const float v = fget<VEC>(b.v[u], k);
             const float adv = gae_step(fget<VEC>(b.r[u], k), v, d, tr, ev, a.g, a.gl, nv[k], na[k]);
             fset<VEC>(out, k, adv);
@@ -127,12 +119,8 @@ __global__ void __launch_bounds__(256) k_gae(GaeArgs a)
     if (col >= (size_t)a.N) return;
 
     float nv[VEC], na[VEC];
-    long idx[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        nv[k] = 0.0f; na[k] = 0.0f;                       // :470-471
-        idx[k] = DENSE_EV ? 0 : a.idx0[col + k];          // :469
-    }
+    for (int k = 0; k < VEC; ++k) { nv[k] = 0.0f; na[k] = 0.0f; }   // :470-471
 
     const int nblk = a.T / U;
     int t = a.T - 1;
@@ -140,14 +128,14 @@ __global__ void __launch_bounds__(256) k_gae(GaeArgs a)
     if (nblk > 0) load_block<VEC, U, DENSE_EV>(cur, a, col, t);
     for (int b = 0; b < nblk; ++b) {
         if (b + 1 < nblk) load_block<VEC, U, DENSE_EV>(nxt, a, col, t - U);  // prefetch next block
-        consume_block<VEC, U, DENSE_EV>(cur, a, col, t, nv, na, idx);
+        consume_block<VEC, U, DENSE_EV>(cur, a, col, t, nv, na);
         cur = nxt;
         t -= U;
     }
     for (; t >= 0; --t) {                                 // T % U leftover rows
         RowBlock<VEC, 1, DENSE_EV> one;
         load_block<VEC, 1, DENSE_EV>(one, a, col, t);
-        consume_block<VEC, 1, DENSE_EV>(one, a, col, t, nv, na, idx);
+        consume_block<VEC, 1, DENSE_EV>(one, a, col, t, nv, na);
     }
 }
 
