@@ -378,10 +378,11 @@ def test_fused_rollout_settles_repeated_truncations_of_one_env():
     assert torch.allclose(ve._ev_dense[tr], want, rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("kind,joint", [("cartpole", 1), ("acrobot", 0)])
+@pytest.mark.parametrize("kind,joint", [("cartpole", 1), ("acrobot", 0), ("acrobot", 1)])
 def test_rollout_is_bit_identical_for_both_wave_widths(kind, joint, request):
     """32 envs per wave (small batches) and 64 envs per wave run the same arithmetic per env: every
-    rollout buffer is bit-identical."""
+    rollout buffer is bit-identical.  (Acrobot's 32-env form also splits each pair of sincos calls between the
+    two lanes that carry an env, csrc/env_core.h Acrobot::trig_of<PAIR>; 333 envs leave a partly filled last wave.)"""
     from ppo_amd import Agent, SyncVecEnv
     from ppo_amd.envs import DeviceEnv
     torch.manual_seed(3)
