@@ -8,7 +8,7 @@ One "step" = one pass of the hot path over one batch, the bracket the reference 
 of the whole-rollout kernel (ppo_rollout_fused: per time step the dense 64-64 tanh policy / value
 network on the matrix cores, Philox action sampling, the fp64 env transition with auto-reset, and, for
 truncated episodes, the bootstrap value of the terminal observation from a second network pass in the
-same kernel) --, the episode-statistics kernels of that rollout (reference :404-417, inside the
+same kernel) --, the episode-statistics kernel of that rollout (reference :404-417, inside the
 reference's bracket too) and the GAE kernel (the trainer's form, ppo_gae_dense_packed, reading the two flag
 bits per element the rollout kernel leaves).  Workload = BASELINE.json configs[1]: CartPole,
 N = 65536 envs x T = 128 per GPU.  With --gpus N every rank runs that workload on its own envs
@@ -348,7 +348,7 @@ def main():
     # (ppo_prof_arm: hipExtLaunchKernelGGL's events time the dispatch packet itself, like rocprofv3 --kernel-trace;
     # a torch.cuda.Event pair around a launch also times two barrier packets and reads 25-50 us high).  Outside the
     # timed region: an event pair costs ~5.7 us of the step it sits in.  A step launches, in this order: the
-    # episode statistics of the PREVIOUS rollout (2 kernels: ppo_episode_stats_incremental_ints), the rollout kernel, GAE.
+    # episode statistics of the PREVIOUS rollout (1 kernel: ppo_episode_stats_incremental_ints), the rollout kernel, GAE.
     us = C.c_float()
 
     def slot_us(slot):
@@ -359,7 +359,8 @@ def main():
         hot_path_step(False)
     per_kernel = []
     bd_t0 = 0.0
-    L, NS = 4, 2                                   # launches per step, of which statistics kernels
+    # launches per step, of which statistics kernels (the override is for A/B runs against an older library build)
+    L, NS = (int(x) for x in os.environ.get("PPO_AMD_BENCH_STEP_LAUNCHES", "3,1").split(","))
     for k in range(16):
         if k == 4:                                 # (first four: settle)
             torch.cuda.synchronize()
@@ -428,7 +429,7 @@ def main():
                                  "input, written by the rollout kernel just before, is served by the 256 MiB Infinity "
                                  "Cache; with HBM-cold inputs (profiles/r03_gae_nt_store_ab.txt) the kernel takes "
                                  "21.2 us, and `traffic` is the L2-to-fabric byte count of such a cold launch"},
-            "step_breakdown_us": {"episode_statistics_2_kernels": float(stats_us),
+            "step_breakdown_us": {"episode_statistics_1_kernel": float(stats_us),
                                   "episode_statistics_each": [float(x) for x in per_kernel[:, :NS].mean(0)],
                                   "k_rollout": float(ro_us),
                                   "k_gae": float(gae_bd_us), "sum": float(stats_us + ro_us + gae_bd_us),
@@ -437,7 +438,7 @@ def main():
                                           "back-to-back steps after the timed region, with the wall time per step of those "
                                           "same twelve steps (every launch carrying an event pair, ~1 us each, so they run "
                                           "a little slower than the timed region's); wall minus sum is dispatch gaps "
-                                          "between the four launches of a step"},
+                                          "between the three launches of a step"},
         }
         line["rollout_kernel"] = {
             "kernel": f"k_rollout (ppo_rollout_fused), {mode_used}", "bound": "valu-issue",

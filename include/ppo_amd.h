@@ -38,7 +38,7 @@ extern "C" {
 /* 2: the sampling stream of ppo_categorical_sample / ppo_rollout_fused draws one Philox block per FOUR policy
  *    steps (counter = step / 4, word = step % 4; version 1 drew one block per step), so a run resumed across the
  *    two versions samples different actions; PPO_NET_BF16X3 added; private hooks changed.
- * 3: ppo_episode_stats_incremental_ints added; nothing else changed. */
+ * 3: ppo_episode_stats_incremental_ints, ppo_episode_stats_ints_hist_offset added; nothing else changed. */
 #define PPO_AMD_ABI_VERSION 3
 
 #define PPO_ENV_CARTPOLE 0 /* CartPole-v1: obs_dim 4, actions {0,1}   */
@@ -414,16 +414,29 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
                                   void *stream);
 
 /*
- * ppo_episode_stats_incremental for rings that hold only values whose f32 pattern has its low 10 bits clear --
- * integers of magnitude below 8192: the returns and lengths of CartPole-v1 / Acrobot-v1 (sums of +-1 rewards and
- * step counts under TimeLimit(500), src/env_cartpole.py:7-8, src/env_acrobot.py:7-8), i.e. everything the env
- * kernels of this library write.  The 22 key bits known after level 1 of the select are then the whole key, so
- * the level-2 pass is not launched at all (two launches per call instead of three; an idle launch costs ~4 us
- * between two kernels of a rollout).  Same state block, same results bit for bit; the two forms may be mixed on
- * one state.  The promise is CHECKED, not trusted: the state counts the window's values with low bits set, and
- * while there is one, stats5 is set to NaN (all five; the running maximum restarts with the next good call)
- * instead of a truncated value.  What SyncVecEnv.rollout calls for the native envs (src/ppo.py:404-417).
+ * The same statistics (src/ppo.py:404-417) for rings that hold only SMALL INTEGERS: returns that are integers in
+ * [-512, 512] and lengths in [0, 512] -- the returns and lengths of CartPole-v1 / Acrobot-v1 (sums of +-1 rewards and
+ * step counts under TimeLimit(500), src/env_cartpole.py:7-8, src/env_acrobot.py:7-8), i.e. everything the env kernels
+ * of this library write.  Such a window is counted directly, one bin per integer, in a persistent histogram that is
+ * updated from the slots written since the previous call (like ppo_episode_stats_incremental) and IS the sorted
+ * window: the nine order statistics are nine positions in its prefix sum.  ONE launch per call -- no radix levels, no
+ * pass that may or may not have work.  Same results as ppo_episode_stats bit for bit.
+ * The promise is CHECKED, not trusted: a value that is not such an integer is counted for as long as it stays in the
+ * window, and while there is one stats5 is set to NaN (all five; the running maximum restarts with the next good
+ * call) instead of a wrong value.  What SyncVecEnv.rollout calls for the native envs.
+ * state: as for ppo_episode_stats_incremental (same size, ppo_episode_stats_state_bytes; zero-filled once, and again
+ * whenever the rings were rewritten by anything else), but the two forms keep different histograms in it: a state
+ * block belongs to ONE of the two entry points -- zero-fill it when switching.
+ * Data-parallel ranks add up the direct histograms (one all-reduce) and read the job's order statistics off the sum:
+ * at byte offset ppo_episode_stats_ints_hist_offset() of the state, u32 [PPO_STATS_INTS_RET_BINS +
+ * PPO_STATS_INTS_LEN_BINS]: word PPO_STATS_INTS_RET_ZERO + r counts the window's returns equal to r, word
+ * PPO_STATS_INTS_RET_BINS + l its lengths equal to l.
  */
+#define PPO_STATS_INTS_RET_ZERO 512
+#define PPO_STATS_INTS_RET_BINS 1280
+#define PPO_STATS_INTS_LEN_BINS 768
+#define PPO_STATS_INTS_LEN_MAX 512
+size_t ppo_episode_stats_ints_hist_offset(void);
 int ppo_episode_stats_incremental_ints(const float *ret_ring, const int *len_ring, const int *ring_cnt,
                                        int ring, int N, double *stats5, void *state, size_t state_bytes,
                                        void *stream);

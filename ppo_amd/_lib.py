@@ -48,6 +48,7 @@ SIGNATURES = {
     "ppo_episode_stats_state_bytes": (_sz, [_i, _i]),
     "ppo_episode_stats_incremental": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ppo_episode_stats_incremental_ints": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "ppo_episode_stats_ints_hist_offset": (_sz, []),
     "ppo_episode_stats_hist0_offset": (_sz, []),
     "ppo_episode_hist_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ppo_rollout_param_floats": (_sz, [_i, _i, _i]),

@@ -243,9 +243,9 @@ __device__ void sel_finalize(double *stats5, const uint32_t *prefix, int bits, u
     stats5[4] = lerp_pair(v[7], v[8], n, 0.50);
 }
 
-// ppo_episode_stats_incremental_ints: the caller promised values whose 22 leading key bits are the whole key (no
-// level-2 launch) and the rings hold one that is not -- the percentiles cannot be finished, so they say so: NaN
-// (the running maximum too; it recovers with the next good call), never a silently truncated value.
+// ppo_episode_stats_incremental_ints: the caller promised small integers and the window holds a value that is not one
+// -- the statistics cannot be made from the direct histogram, so they say so: NaN (the running maximum too; it
+// recovers with the next good call), never a silently wrong value.
 __device__ void sel_poison(double *stats5)
 {
     for (int k = 0; k < 5; ++k) stats5[k] = __longlong_as_double(0x7ff8000000000000ll);
@@ -266,7 +266,7 @@ __device__ unsigned long long sel_target_rank(int t, unsigned long long n)
 // no episode has finished, like the reference's attributes (src/ppo.py:250-254, :408-417).
 // INCR (incremental form): hist0 and hist1 persist between calls and are never cleared here, and
 // whether level 2 is needed comes from the state's running count `nz` instead of this pass.
-template <int LEVEL, bool INCR> __device__ void sel_narrow(const SelWs &w, const uint32_t *hist, double *stats5, int ints_only)
+template <int LEVEL, bool INCR> __device__ void sel_narrow(const SelWs &w, const uint32_t *hist, double *stats5)
 {
     __shared__ unsigned long long s_rank[SEL_T];
     __shared__ uint32_t s_prefix[SEL_T];
@@ -328,11 +328,6 @@ template <int LEVEL, bool INCR> __device__ void sel_narrow(const SelWs &w, const
     if (LEVEL == 0) __hip_atomic_store(&st->low_bits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (LEVEL == 1) st->skip2 = last ? 1 : 0;
     if (LEVEL == 1 && INCR) st->skip1 = 1;                   // the tracked histograms are complete again
-    if (LEVEL == 1 && INCR && !last && ints_only) {          // the caller launches no level 2 (see sel_poison)
-        st->skip2 = 1;
-        sel_poison(stats5);
-        return;
-    }
     if (!last) sel_setup_next(st, s_prefix, s_rank, n, false);
     else sel_finalize(stats5, s_prefix, LEVEL == 1 ? 22 : 32, n);
 }
@@ -419,7 +414,7 @@ __device__ __forceinline__ void sel_walk(const float *ret_ring, const int *len_r
 
 template <int LEVEL, bool INCR>
 __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, const int *len_ring, const int *ring_cnt,
-                                                      int ring, int N, SelWs w, double *stats5, int ints_only)
+                                                      int ring, int N, SelWs w, double *stats5)
 {
     constexpr int NH = LEVEL == 0 ? 2 : SEL_T, NB = LEVEL == 0 ? SEL_B0 : SEL_B1;
     __shared__ uint32_t h[LEVEL == 0 ? SEL_H0_LDS : NH * NB];   // level 0: room for the padded copy the narrowing reads
@@ -470,7 +465,7 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_sel(const float *ret_ring, co
     __syncthreads();                                         // (level 0: every thread is done with the unpadded layout)
     f.template store<LEVEL == 0>(h);
     __syncthreads();
-    sel_narrow<LEVEL, INCR>(w, h, stats5, ints_only);
+    sel_narrow<LEVEL, INCR>(w, h, stats5);
 }
 
 // Histogram pass alone, for a selection that is narrowed OUTSIDE this library: data-parallel ranks add up their
@@ -504,10 +499,9 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 2) k_hist_level(const float *ret_r
 
 template <int LEVEL, bool INCR = false>
 int sel_level(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N, const SelWs &w,
-              double *stats5, unsigned blocks, hipStream_t s, int ints_only = 0)
+              double *stats5, unsigned blocks, hipStream_t s)
 {
-    PPO_LAUNCH((k_sel<LEVEL, INCR>), dim3(blocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5,
-               ints_only);
+    PPO_LAUNCH((k_sel<LEVEL, INCR>), dim3(blocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, w, stats5);
     return ppo_launch_status();
 }
 
@@ -555,7 +549,7 @@ constexpr int INCR_ENVS = 256;           // envs a workgroup takes per pass (the
 
 __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr(const float *__restrict__ ret_ring, const int *__restrict__ len_ring,
                                                            const int *__restrict__ ring_cnt, int ring, int N, SelWs w,
-                                                           IncrBufs ib, double *stats5, int ints_only)
+                                                           IncrBufs ib, double *stats5)
 {
     __shared__ uint32_t h0[SEL_H0_LDS];                        // deltas in the first 2 * SEL_B0 words; later the padded copy
     __shared__ uint32_t h1[SEL_T * SEL_B1];
@@ -741,14 +735,186 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr(const float *__restr
         st->n = n;
         st->skip2 = 1;
         sel_finalize(stats5, s_prefix, 22, n);
-    } else if (ints_only) {                                    // ... and the caller launches no level 2 (see sel_poison)
-        st->n = n;
-        st->skip2 = 1;
-        sel_poison(stats5);
     } else {                                                   // values with low float bits set: level 2 over the rings
         sel_setup_next(st, s_prefix, s_rank, n, false);
         st->skip2 = 0;
     }
+}
+
+// ---- incremental form for small integers: ONE launch, one level -------------------------------------
+// What the env kernels of this library write into the rings are small integers: returns are sums of +-1 rewards under
+// TimeLimit(500) (|return| <= 500), lengths step counts <= 500.  For such rings the window's values can be counted
+// DIRECTLY -- one bin per integer -- instead of by key digits: returns in [-512, 512] into 1025 bins, lengths in
+// [0, 512] into 513.  The persistent histogram is then the sorted window itself: nine ranks are nine positions in a
+// prefix sum over ~1.5 k bins, there are no levels, no tracked prefixes and no pass that may or may not have work --
+// k_sel_incr's two fallback launches (a kernel boundary each, ~4.5 us idle) are gone, and the LDS clear, the flush
+// and the last workgroup's read-back shrink from 17 k words to 2 k.  The walk over the newly written slots and the
+// shadow copy are k_sel_incr's.  A value that is not a small integer is counted in `bad` for as long as it stays in
+// the window and turns the statistics into NaN (sel_poison): the promise is checked, not trusted.
+constexpr int INTS_R0 = PPO_STATS_INTS_RET_ZERO;           // bin of return 0
+constexpr int INTS_RBINS = PPO_STATS_INTS_RET_BINS;        // 1280 = 64 lanes x 20 (1025 used)
+constexpr int INTS_LBINS = PPO_STATS_INTS_LEN_BINS;        // 768 = 64 lanes x 12 (513 used)
+constexpr int INTS_WORDS = INTS_RBINS + INTS_LBINS;
+static_assert(INTS_RBINS % 256 == 0 && INTS_LBINS % 256 == 0 && INTS_R0 * 2 + 1 <= INTS_RBINS, "bin layout");
+
+struct IntsState {                // head of the state block (the first SEL_STATE_BYTES bytes), zero-filled by the caller
+    unsigned long long n;         // valid window entries at the last call
+    long long bad;                // window entries that are not small integers
+    uint32_t ticket;
+};
+static_assert(sizeof(IntsState) <= SEL_STATE_BYTES, "state head too small");
+
+__device__ __forceinline__ void ints_apply(uint32_t *h, uint32_t sign, float r, int l, int &bad)
+{
+    const int ri = (int)r;                                     // (saturates for huge values, which then fail the range test)
+    const bool ok = (float)ri == r && ri >= -INTS_R0 && ri <= INTS_R0 && l >= 0 && l <= PPO_STATS_INTS_LEN_MAX;
+    if (ok) {
+        atomicAdd(&h[INTS_R0 + ri], sign);
+        atomicAdd(&h[INTS_RBINS + l], sign);
+    } else {
+        bad += (int)sign;                                      // +1 entering, -1 (0xffffffff) leaving
+    }
+}
+
+__global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr_ints(const float *__restrict__ ret_ring, const int *__restrict__ len_ring,
+                                                                const int *__restrict__ ring_cnt, int ring, int N,
+                                                                IntsState *st, uint32_t *hist, IncrBufs ib, double *stats5)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t h[INTS_WORDS];
+    __shared__ int s_is_last;
+    __shared__ int s_bin[SEL_T];
+    __shared__ unsigned long long s_n;
+    __shared__ uint32_t s_first[INCR_ENVS + 1];
+    __shared__ int s_c0[INCR_ENVS], s_c1[INCR_ENVS];
+    __shared__ uint32_t s_wsum[INCR_ENVS / 64];
+    uint2 *__restrict__ shadow = ib.shadow;
+    for (int k = threadIdx.x; k < INTS_WORDS; k += SEL_HBLOCK) h[k] = 0u;
+
+    // the slots written since the last call, exactly as in k_sel_incr
+    const uint32_t uring = (uint32_t)ring;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int bad = 0;
+    for (int env0 = blockIdx.x * INCR_ENVS; env0 < N; env0 += gridDim.x * INCR_ENVS) {
+        __syncthreads();
+        uint32_t m = 0, incl = 0;
+        int c0 = 0, c1 = 0;
+        if (threadIdx.x < INCR_ENVS) {
+            const int n = env0 + threadIdx.x;
+            if (n < N) {
+                c1 = max(ring_cnt[n], 0);
+                c0 = ib.cnt_prev[n];
+                m = (uint32_t)max(min(c1 - c0, ring), 0);
+                if (m > 0) ib.cnt_prev[n] = c1;
+            }
+            incl = m;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) s_wsum[wv] = incl;
+            s_c0[threadIdx.x] = c0;
+            s_c1[threadIdx.x] = c1;
+        }
+        __syncthreads();
+        if (threadIdx.x < INCR_ENVS) {
+            uint32_t before = 0;
+            for (int q = 0; q < wv; ++q) before += s_wsum[q];
+            s_first[threadIdx.x] = before + incl - m;
+            if (threadIdx.x == INCR_ENVS - 1) s_first[INCR_ENVS] = before + incl;
+        }
+        __syncthreads();
+        const uint32_t items = s_first[INCR_ENVS];
+        for (uint32_t it0 = threadIdx.x; it0 < items; it0 += 2 * SEL_HBLOCK) {
+            size_t at[2];
+            bool live[2], old_valid[2];
+            float r_new[2], r_old[2];
+            int l_new[2], l_old[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t it = it0 + u * SEL_HBLOCK;
+                live[u] = it < items;
+                int e = 0;
+#pragma unroll
+                for (int stepb = INCR_ENVS / 2; stepb > 0; stepb >>= 1)
+                    if (s_first[e + stepb] <= it) e += stepb;
+                if (!live[u]) e = 0;
+                const uint32_t first = s_first[e], cnt_e = s_first[e + 1] - first;
+                const int ec0 = s_c0[e], ec1 = s_c1[e];
+                const uint32_t i = (uint32_t)ec1 - cnt_e + (it - first);
+                const uint32_t slot = live[u] ? i % uring : 0u;
+                at[u] = (size_t)(env0 + e) * uring + slot;
+                old_valid[u] = live[u] && (ec0 >= ring || slot < (uint32_t)ec0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                r_new[u] = ret_ring[at[u]]; l_new[u] = len_ring[at[u]];
+                const uint2 old = shadow[at[u]];
+                r_old[u] = __uint_as_float(old.x); l_old[u] = (int)old.y;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (live[u]) {
+                    shadow[at[u]] = make_uint2(__float_as_uint(r_new[u]), (uint32_t)l_new[u]);
+                    ints_apply(h, 1u, r_new[u], l_new[u], bad);
+                }
+                if (old_valid[u]) ints_apply(h, 0xFFFFFFFFu, r_old[u], l_old[u], bad);
+            }
+        }
+    }
+    bad = (int)wave_sum((double)bad);
+    if ((threadIdx.x & 63) == 0 && bad != 0)
+        __hip_atomic_fetch_add(&st->bad, (long long)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int k = threadIdx.x; k < INTS_WORDS; k += SEL_HBLOCK) {
+        const uint32_t v = h[k];
+        if (v) atomicAdd(&hist[k], v);
+    }
+    // last workgroup to flush makes the statistics (see k_sel for why atomics + vmcnt(0) and no fence)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_is_last = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_is_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SelFetch<INTS_WORDS> f;
+    f.fetch(hist);
+    const long long bad_now = threadIdx.x == 0 ? __hip_atomic_load(&st->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();                                         // every thread is done with the deltas
+    f.template store<false>(h);
+    __syncthreads();
+    const int t = wv;                                        // waves 0..8: one target each
+    if (t < SEL_SWAVES) {
+        unsigned long long n = 0, rank = 0;
+        int bin = 0;
+        if (t < SEL_T_RET) {
+            WaveBins<INTS_RBINS / 64> wb;
+            wb.load(h);
+            n = wb.total;
+            if (n > 0) { rank = sel_target_rank(t, n); bin = wb.find(rank); }
+        } else {
+            WaveBins<INTS_LBINS / 64> wb;
+            wb.load(h + INTS_RBINS);
+            n = wb.total;
+            if (n > 0) { rank = sel_target_rank(t, n); bin = wb.find(rank); }
+        }
+        if (lane == 0) s_bin[t] = bin;
+        if (threadIdx.x == 0) s_n = n;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const unsigned long long n = s_n;
+    st->n = n;
+    if (bad_now != 0) { sel_poison(stats5); return; }
+    if (n == 0) return;                                      // nothing finished yet: stats5 keeps its value (NaN at start)
+    double v[SEL_T];
+    for (int u = 0; u < SEL_T; ++u) v[u] = u < SEL_T_RET ? (double)(s_bin[u] - INTS_R0) : (double)s_bin[u];
+    if (!(stats5[0] >= v[6])) stats5[0] = v[6];              // also replaces the initial NaN
+    stats5[1] = lerp_pair(v[0], v[1], n, 0.05);
+    stats5[2] = lerp_pair(v[2], v[3], n, 0.50);
+    stats5[3] = lerp_pair(v[4], v[5], n, 0.95);
+    stats5[4] = lerp_pair(v[7], v[8], n, 0.50);
 }
 
 }  // namespace
@@ -806,8 +972,8 @@ size_t ppo_episode_stats_state_bytes(int N, int ring)
     return incr_state_bytes(N, ring);
 }
 
-static int episode_stats_incremental(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
-                                     double *stats5, void *state, size_t state_bytes, void *stream, int ints_only)
+int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
+                                  double *stats5, void *state, size_t state_bytes, void *stream)
 {
     PPO_REQUIRE(N >= 0 && ring > 0 && (unsigned long long)N * (unsigned long long)ring < 0xFFFFFFFFull);
     PPO_REQUIRE(stats5 && ppo_aligned(stats5, 8));
@@ -823,7 +989,7 @@ static int episode_stats_incremental(const float *ret_ring, const int *len_ring,
     size_t iblocks = ((size_t)N + INCR_ENVS - 1) / INCR_ENVS;
     if (iblocks > 256) iblocks = 256;
     PPO_LAUNCH(k_sel_incr, dim3((unsigned)iblocks), dim3(SEL_HBLOCK), s, ret_ring, len_ring, ring_cnt, ring, N, w,
-                       ib, stats5, ints_only);
+                       ib, stats5);
     int rc = ppo_launch_status();
     if (rc) return rc;
     // the two full passes: return at once unless a wanted prefix is untracked (level 1) or values are
@@ -833,21 +999,34 @@ static int episode_stats_incremental(const float *ret_ring, const int *len_ring,
     size_t blocks = ((size_t)N * ring + SEL_HBLOCK * SEL_U - 1) / (SEL_HBLOCK * SEL_U);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    rc = sel_level<1, true>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s, ints_only);
-    if (rc || ints_only) return rc;                  // (ints_only: level 1 always ends the selection, or poisons it)
+    rc = sel_level<1, true>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
+    if (rc) return rc;
     return sel_level<2, true>(ret_ring, len_ring, ring_cnt, ring, N, w, stats5, (unsigned)blocks, s);
 }
 
-int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
-                                  double *stats5, void *state, size_t state_bytes, void *stream)
-{
-    return episode_stats_incremental(ret_ring, len_ring, ring_cnt, ring, N, stats5, state, state_bytes, stream, 0);
-}
+size_t ppo_episode_stats_ints_hist_offset(void) { return SEL_STATE_BYTES; }
 
 int ppo_episode_stats_incremental_ints(const float *ret_ring, const int *len_ring, const int *ring_cnt, int ring, int N,
                                        double *stats5, void *state, size_t state_bytes, void *stream)
 {
-    return episode_stats_incremental(ret_ring, len_ring, ring_cnt, ring, N, stats5, state, state_bytes, stream, 1);
+    PPO_REQUIRE(N >= 0 && ring > 0 && (unsigned long long)N * (unsigned long long)ring < 0xFFFFFFFFull);
+    PPO_REQUIRE(stats5 && ppo_aligned(stats5, 8));
+    PPO_REQUIRE(state && state_bytes >= incr_state_bytes(N, ring) && ppo_aligned(state, 16));
+    static_assert(SEL_STATE_BYTES + INTS_WORDS * sizeof(uint32_t) <= INCR_HEAD_BYTES, "direct histogram fits the state head");
+    if (N == 0) return 0;
+    PPO_REQUIRE(ret_ring && len_ring && ring_cnt);
+    char *base = static_cast<char *>(state);
+    IntsState *st = reinterpret_cast<IntsState *>(base);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(base + SEL_STATE_BYTES);
+    char *p = base + INCR_HEAD_BYTES;
+    IncrBufs ib;
+    ib.cnt_prev = reinterpret_cast<int *>(p);
+    ib.shadow = reinterpret_cast<uint2 *>(p + incr_cnt_bytes(N));
+    size_t iblocks = ((size_t)N + INCR_ENVS - 1) / INCR_ENVS;
+    if (iblocks > 256) iblocks = 256;
+    PPO_LAUNCH(k_sel_incr_ints, dim3((unsigned)iblocks), dim3(SEL_HBLOCK), (hipStream_t)stream, ret_ring, len_ring, ring_cnt,
+               ring, N, st, hist, ib, stats5);
+    return ppo_launch_status();
 }
 
 }  // extern "C"

@@ -542,9 +542,9 @@ class SyncVecEnv:
         """Data parallel: the reference's statistics tail (src/ppo.py:404-417) over the deques of ALL envs of the
         job, not of this rank's shard -- running max, 5/50/95 percentiles of the returns, median length -- and the
         job's reward sum of the last rollout (:318, :348), which it returns.  EVERY rank must call it, once per
-        update (collectives: one gather of two floats per rank, then one histogram sum per level of the radix
-        select -- 32 KB and 36 KB -- narrowed identically on every rank's host).  Exact: the same nine order
-        statistics ppo_episode_stats selects, np.percentile's "linear" interpolation."""
+        update (collectives: one gather of three floats per rank, then ONE sum of the ranks' direct histograms,
+        8 KB, read identically on every rank's host).  Exact: the same nine order statistics ppo_episode_stats
+        selects, np.percentile's "linear" interpolation."""
         if not self.native:
             return self._job_wide_host_stats()
         lib = ops._lib.load()
@@ -554,50 +554,33 @@ class SyncVecEnv:
         tr = self._total_return
         tr = tr.detach().to(torch.float64).reshape(1) if isinstance(tr, torch.Tensor) else torch.tensor([float(tr)], dtype=torch.float64)
         own_max = self._stats5[0:1] if self._stats5 is not None else torch.full((1,), float("nan"), dtype=torch.float64, device=dev)
-        pair = torch.cat([torch.nan_to_num(own_max, nan=-float("inf")).to(dev), tr.to(dev)])
+        # (IntsState of csrc/stats.hip: the count of window entries that are not small integers is the i64 at byte 8)
+        own_bad = (self._stats_state[8:16].view(torch.int64).to(torch.float64) if self._stats_state is not None
+                   else torch.zeros(1, dtype=torch.float64, device=dev))
+        pair = torch.cat([torch.nan_to_num(own_max, nan=-float("inf")).to(dev), tr.to(dev), own_bad.to(dev)])
         rows = ppo_dist.gather_rows(pair, "ep_max_and_reward_sum").cpu().numpy()
-        job_max, job_reward = float(rows[:, 0].max()), float(rows[:, 1].sum())
+        job_max, job_reward, job_bad = float(rows[:, 0].max()), float(rows[:, 1].sum()), float(np.abs(rows[:, 2]).sum())
         self._stats_dev = None
         if self._stats_state is None:                      # no rollout yet
             return job_reward
-        off = lib.ppo_episode_stats_hist0_offset()
-        h0 = self._stats_state[off:off + 2 * 4096 * 4].view(torch.int32).clone()
-        h0 = ppo_dist.sum_tensor(h0, "ep_hist0").cpu().numpy().view(np.uint32).reshape(2, 4096).astype(np.int64)
-        n = int(h0[0].sum())
+        # the incremental statistics keep the window as a DIRECT histogram (one bin per integer return / length,
+        # ppo_episode_stats_incremental_ints): the job's window is the sum of the ranks' histograms, and the nine order
+        # statistics are nine positions in its prefix sum
+        RB, R0 = _lib_const("PPO_STATS_INTS_RET_BINS"), _lib_const("PPO_STATS_INTS_RET_ZERO")
+        LB = _lib_const("PPO_STATS_INTS_LEN_BINS")
+        off = lib.ppo_episode_stats_ints_hist_offset()
+        h = self._stats_state[off:off + (RB + LB) * 4].view(torch.int32).clone()
+        h = ppo_dist.sum_tensor(h, "ep_hist_ints").cpu().numpy().view(np.uint32).astype(np.int64)
+        n = int(h[:RB].sum())
         if n == 0:                                         # no episode has finished anywhere yet
             return job_reward
-        ranks = _select_ranks(n)
-        c0 = [np.cumsum(h0[0]), np.cumsum(h0[1])]
-        pref, resid = [], []
-        for t, r in enumerate(ranks):
-            bkt, rem = _bucket_of(c0[0 if t < 7 else 1], r)
-            pref.append(bkt)
-            resid.append(rem)
-        for level in (1, 2):
-            lists = [sorted(set(pref[:7])), sorted(set(pref[7:]))]
-            table = np.full(9, 0xFFFFFFFF, dtype=np.uint32)
-            table[:len(lists[0])] = lists[0]
-            table[7:7 + len(lists[1])] = lists[1]
-            d_table = torch.from_numpy(table.view(np.int32)).to(dev)
-            hist = torch.zeros(9 * 1024 + 1, dtype=torch.int32, device=dev)
-            ops._lib.check(lib.ppo_episode_hist_level(b.ret_ring.data_ptr(), b.len_ring.data_ptr(), b.ring_cnt.data_ptr(),
-                                                      b.ring, b.num_envs, level, d_table.data_ptr(), len(lists[0]),
-                                                      len(lists[1]), hist.data_ptr(), ops._stream()),
-                           "ppo_episode_hist_level")
-            hist = ppo_dist.sum_tensor(hist, f"ep_hist{level}").cpu().numpy().view(np.uint32).astype(np.int64)
-            rowsum = np.cumsum(hist[:9 * 1024].reshape(9, 1024), axis=1)
-            for t in range(9):
-                row = lists[0].index(pref[t]) if t < 7 else 7 + lists[1].index(pref[t])
-                bkt, resid[t] = _bucket_of(rowsum[row], resid[t])
-                pref[t] = (pref[t] << 10) | bkt
-            if level == 1 and hist[9 * 1024] == 0:         # integer-valued statistics: 22 key bits are the whole key
-                pref = [(p << 10) | (0 if (p >> 21) & 1 else 1023) for p in pref]
-                break
-        v = _key_to_float(np.array(pref, dtype=np.uint64))
-        self._note_stats([job_max if job_max > -float("inf") else v[6], _lerp(v[0], v[1], n, 0.05), _lerp(v[2], v[3], n, 0.50),
-                          _lerp(v[4], v[5], n, 0.95), _lerp(v[7], v[8], n, 0.50)])
-        if not (self._stats_host["max"] >= v[6]):
-            self._stats_host["max"] = np.float32(v[6])
+        if job_bad != 0:                                   # a value that is not a small integer somewhere in the job's window
+            self._note_stats([float("nan")] * 5)
+            return job_reward
+        win_max, p5, p50, p95, med_len = _direct_select(h[:RB], h[RB:], R0)
+        self._note_stats([job_max if job_max > -float("inf") else win_max, p5, p50, p95, med_len])
+        if not (self._stats_host["max"] >= win_max):
+            self._stats_host["max"] = np.float32(win_max)
         return job_reward
 
     def _job_wide_host_stats(self) -> float:
@@ -725,6 +708,14 @@ class SyncVecEnv:
             self.median_ep_length = np.float64(_percentiles(srt, (50.0,)).item())
 
 
+_LIB_CONSTS = {"PPO_STATS_INTS_RET_ZERO": 512, "PPO_STATS_INTS_RET_BINS": 1280, "PPO_STATS_INTS_LEN_BINS": 768,
+               "PPO_STATS_INTS_LEN_MAX": 512}      # include/ppo_amd.h (tests/test_abi.py checks them against the header)
+
+
+def _lib_const(name: str) -> int:
+    return _LIB_CONSTS[name]
+
+
 def _select_ranks(n: int):
     """Ranks (0-based, among n values) of the nine order statistics behind the reference's statistics: lower / upper
     neighbour of the 5th, 50th and 95th percentile of the returns (np.percentile, method "linear"), their maximum,
@@ -740,6 +731,17 @@ def _bucket_of(cum: np.ndarray, rank: int):
     """(bucket holding the entry of 0-based rank `rank`, its rank inside that bucket) from inclusive counts."""
     bkt = int(np.searchsorted(cum, rank, side="right"))
     return bkt, rank - (int(cum[bkt - 1]) if bkt > 0 else 0)
+
+
+def _direct_select(h_ret: np.ndarray, h_len: np.ndarray, ret_zero: int):
+    """[window max, p5, p50, p95 of the returns, median length] from DIRECT histograms (csrc/stats.hip k_sel_incr_ints:
+    h_ret[ret_zero + r] counts returns equal to the integer r, h_len[l] lengths equal to l): the reference's np.max /
+    np.percentile (src/ppo.py:407-417) read off two prefix sums."""
+    n = int(h_ret.sum())
+    ranks = _select_ranks(n)
+    cum = [np.cumsum(h_ret), np.cumsum(h_len)]
+    v = [float(_bucket_of(cum[0], r)[0] - ret_zero) if t < 7 else float(_bucket_of(cum[1], r)[0]) for t, r in enumerate(ranks)]
+    return [v[6], _lerp(v[0], v[1], n, 0.05), _lerp(v[2], v[3], n, 0.50), _lerp(v[4], v[5], n, 0.95), _lerp(v[7], v[8], n, 0.50)]
 
 
 def _key_to_float(keys: np.ndarray) -> np.ndarray:

@@ -49,6 +49,14 @@ def test_abi_version_and_obs_dim():
     assert lib.ppo_env_obs_dim(0) == 4 and lib.ppo_env_obs_dim(1) == 6 and lib.ppo_env_obs_dim(7) == -1
 
 
+def test_header_constants_match_the_python_side():
+    from ppo_amd.ppo import _LIB_CONSTS
+    text = open(os.path.join(ROOT, "include", "ppo_amd.h")).read()
+    for name, value in _LIB_CONSTS.items():
+        m = re.search(r"#define\s+%s\s+(\d+)" % name, text)
+        assert m and int(m.group(1)) == value, name
+
+
 def test_argument_validation_rejects_before_launch():
     lib = _lib.load()
     INVALID = 1  # hipErrorInvalidValue

@@ -7,7 +7,9 @@ Covered: nothing finished yet; calls with nothing new; more than `ring` new epis
 two calls; rings that have not wrapped; integer returns (CartPole), negative integers (Acrobot) -- the
 paths that end without a full pass --; a drifting distribution (percentiles move to other key
 prefixes: the level-1 histograms are rebuilt); non-integer floats (level 2 over the rings every call);
-ring lengths other than 100; the state re-zeroed after the rings were rewritten."""
+ring lengths other than 100; the state re-zeroed after the rings were rewritten.
+ppo_episode_stats_incremental_ints (the one-launch direct-histogram form a rollout calls) runs beside it on a state
+of its own: identical statistics for integer rings, NaN while a value that is not a small integer is in the window."""
 import ctypes as C
 import zlib
 
@@ -24,6 +26,12 @@ class SelState(C.Structure):      # mirror of csrc/stats.hip SelState, only to r
                 ("lslot", C.c_int * 9), ("ticket", C.c_uint32), ("low_bits", C.c_uint32), ("skip2", C.c_int),
                 ("skip1", C.c_int), ("ntrack_ret", C.c_int), ("ntrack", C.c_int), ("tprefix", C.c_uint32 * 9),
                 ("tslot", C.c_int * 9), ("nz", C.c_int64)]
+
+
+def _ints_head(state):
+    """(n, bad) of csrc/stats.hip IntsState, the head of a state block used by ppo_episode_stats_incremental_ints."""
+    raw = state[:16].cpu().numpy().tobytes()
+    return int.from_bytes(raw[:8], "little"), int.from_bytes(raw[8:16], "little", signed=True)
 
 
 def _flags(state):
@@ -90,7 +98,7 @@ def test_incremental_statistics_follow_the_deques(case):
     ws = torch.zeros(lib.ppo_episode_stats_workspace_bytes(), dtype=torch.uint8, device="cuda")
     s_inc = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
     s_full = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
-    # the two-launch form for small integers (what a rollout calls), on a state block of its own
+    # the one-launch direct-histogram form for small integers (what a rollout calls), on a state block of its own
     state_i = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     s_int = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
     running_max = None
@@ -132,9 +140,9 @@ def test_incremental_statistics_follow_the_deques(case):
         ints = s_int.cpu().numpy()
         if case != "floats":                             # integer-valued: the same numbers without the third launch
             assert np.array_equal(ints, got), (case, c, ints, got)
-        else:                                            # promise broken: NaN, never a truncated value
-            assert (_flags(state_i)[2] != 0) and np.isnan(ints).all(), (case, c, ints)
-        assert _flags(state_i)[1] == 1                   # level 2 is never asked for
+        else:                                            # promise broken: NaN, never a wrong value
+            assert _ints_head(state_i)[1] != 0 and np.isnan(ints).all(), (case, c, ints)
+        assert _ints_head(state_i)[0] == (n if case != "floats" else _ints_head(state_i)[0])
     if case in ("cartpole_ints", "acrobot_negative", "constant"):
         assert fast_calls >= calls - 2, fast_calls       # steady distributions: no full pass after the first calls
     # the rings rewritten behind the state's back (a restored checkpoint): zero the state, start over
@@ -182,5 +190,44 @@ def test_incremental_statistics_at_bench_scale_through_rollouts():
     want = np.percentile(r.cpu().numpy().astype(np.float64), [5.0, 50.0, 95.0])
     assert np.allclose(s_inc.cpu().numpy()[1:4], want, rtol=1e-12, atol=0.0)
     assert all(fast[2:]), fast
-    ve._flush_stats()                                    # the rollouts' own statistics: the two-launch integer form
+    ve._flush_stats()                                    # the rollouts' own statistics: the one-launch integer form
     assert torch.equal(ve._stats5, s_inc), (ve._stats5, s_inc)
+
+
+def test_direct_histogram_form_bounds_and_recovery():
+    """ppo_episode_stats_incremental_ints at the edges of its promise: returns of exactly +-512 and lengths of 512 are
+    counted; 513 (an integer, but outside the bins), 0.5 and a length of 513 make the statistics NaN for exactly as
+    long as they are in the window, and the numbers are right again once the ring has pushed them out."""
+    from ppo_amd import _lib
+    lib = _lib.load()
+    ring, N = 4, 96
+    rng = np.random.default_rng(5)
+    h = HostRings(N, ring)
+    d_ret, d_len, d_cnt = (torch.from_numpy(x).cuda() for x in (h.ret, h.len, h.cnt))
+    state = torch.zeros(lib.ppo_episode_stats_state_bytes(N, ring), dtype=torch.uint8, device="cuda")
+    s5 = torch.full((5,), float("nan"), dtype=torch.float64, device="cuda")
+
+    def push(counts, draw_ret, draw_len):
+        h.append(counts, draw_ret, draw_len)
+        d_ret.copy_(torch.from_numpy(h.ret)); d_len.copy_(torch.from_numpy(h.len)); d_cnt.copy_(torch.from_numpy(h.cnt))
+        assert lib.ppo_episode_stats_incremental_ints(d_ret.data_ptr(), d_len.data_ptr(), d_cnt.data_ptr(), ring, N,
+                                                      s5.data_ptr(), state.data_ptr(), state.numel(), None) == 0
+        torch.cuda.synchronize()
+        return s5.cpu().numpy()
+
+    every = np.full(N, 3, np.int32)
+    got = push(every, lambda k: rng.choice([-512.0, 512.0, 0.0, 7.0], k).astype(np.float32),
+               lambda k: rng.choice([1, 512, 500], k).astype(np.int32))
+    want = _want(h)
+    assert got[0] == want[0] == 512.0 and np.allclose(got[1:4], want[1:4], rtol=1e-12, atol=0.0) and got[4] == want[4]
+    assert _ints_head(state) == (3 * N, 0)
+    one = np.zeros(N, np.int32); one[5] = 1
+    for bad_ret, bad_len in ((513.0, 10), (0.5, 10), (3.0, 513), (float("inf"), 3)):
+        got = push(one, lambda k: np.full(k, bad_ret, np.float32), lambda k: np.full(k, bad_len, np.int32))
+        assert np.isnan(got).all() and _ints_head(state)[1] == 1, (bad_ret, bad_len, got)
+        four = np.zeros(N, np.int32); four[5] = ring             # the ring of env 5 turns over: the value leaves the window
+        got = push(four, lambda k: rng.integers(-20, 20, k).astype(np.float32), lambda k: rng.integers(1, 400, k).astype(np.int32))
+        want = _want(h)
+        assert _ints_head(state)[1] == 0
+        # (the running maximum restarts after a NaN: it is the window's maximum now)
+        assert got[0] == want[0] and np.allclose(got[1:4], want[1:4], rtol=1e-12, atol=0.0) and got[4] == want[4], (got, want)

@@ -230,3 +230,12 @@ def test_job_wide_selection_equals_numpy_percentile(kind):
     got = _select_like_the_ranks_do(rets, lens)
     want = [rets.max(), *np.percentile(rets.astype(np.float64), [5, 50, 95]), np.percentile(lens.astype(np.float64), 50)]
     assert np.array_equal(np.array(got, dtype=np.float64), np.array(want, dtype=np.float64)), (got, want)
+    if kind in ("integers", "negative_integers", "duplicates"):
+        # what SyncVecEnv.job_wide_episode_stats runs for the native envs: the (all-reduced) DIRECT histograms of
+        # ppo_episode_stats_incremental_ints, one bin per integer
+        from ppo_amd.ppo import _direct_select, _lib_const
+        R0, RB, LB = (_lib_const("PPO_STATS_INTS_" + k) for k in ("RET_ZERO", "RET_BINS", "LEN_BINS"))
+        h_ret = np.bincount(rets.astype(np.int64) + R0, minlength=RB)
+        h_len = np.bincount(lens.astype(np.int64), minlength=LB)
+        got = _direct_select(h_ret, h_len, R0)
+        assert np.array_equal(np.array(got, dtype=np.float64), np.array(want, dtype=np.float64)), (got, want)

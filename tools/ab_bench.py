@@ -26,5 +26,5 @@ else:
             d = json.loads(line[-1])
             b = d["step_breakdown_us"]
             print(f"{os.path.basename(lib):24s} {d['ms_per_step'] * 1e3:7.1f} us/step  f32-grade {d['ms_per_step_f32_grade'] * 1e3:7.1f}  "
-                  f"gae(timed region) {d['roofline']['avg_launch_us']:5.2f}  breakdown: stats {b.get('episode_statistics_2_kernels', b.get('episode_statistics_3_kernels')):5.1f} "
+                  f"gae(timed region) {d['roofline']['avg_launch_us']:5.2f}  breakdown: stats {next(v for k, v in b.items() if k.startswith('episode_statistics_') and k != 'episode_statistics_each'):5.1f} "
                   f"rollout {b['k_rollout']:6.1f} gae {b['k_gae']:5.2f}", flush=True)
