@@ -419,6 +419,11 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes,
+                         # the same kernel in the twelve fully instrumented steps behind the timed region (every launch of
+                         # the step timestamped, as under rocprofv3 --kernel-trace, whose mean this one matches): a GAE
+                         # launch timed ALONE right behind the un-timed rollout kernel reads 1-2 us longer
+                         "avg_launch_us_instrumented_steps": float(gae_bd_us),
+                         "frac_instrumented_steps": gae_bytes / (float(gae_bd_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "achieved_at_api_20B_per_elem": 20 * T * N / (gae_ms * 1e-3) / 1e9,
                          "achieved_if_dense_24B_per_elem": 24 * T * N / (gae_ms * 1e-3) / 1e9,
                          "note": "algorithmic bytes = what this kernel has to move: 12.25 B/element (r, v, two flag bits "
