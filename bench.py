@@ -83,8 +83,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-train-step", action="store_true")
     p.add_argument("--train-step-timeout", type=float, default=240.0)
-    p.add_argument("--gae-event-every", type=int, default=4,
-                   help="time every K-th GAE dispatch of the timed region with a start/stop event pair (0: none)")
+    p.add_argument("--gae-event-every", type=int, default=8,
+                   help="in every K-th step of the timed region all launches carry start/stop event pairs; the GAE "
+                        "kernel's duration for `roofline` comes from those steps (0: none)")
     p.add_argument("--cpu-sample-envs", type=int, default=4096)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--sustained-seconds", type=float, default=2.0,
@@ -244,30 +245,33 @@ def main():
 
     gae_events = []
     step_no = [0]
+    SAMPLE_SLOTS = 4                               # launches of a step are at most this many (three today)
 
     def hot_path_step(record):
-        # every K-th GAE launch of the timed region carries a start/stop event pair.  A pair costs ~5.7 us of
-        # the step it sits in (measured: 0.4906 / 0.4862 / 0.4855 / 0.4850 ms per step for K = 1 / 4 / 8 / none), so
-        # the default samples every fourth launch: ~1.5 us per step on average, 12 samples in 50 steps
+        # In every K-th step of the timed region ALL launches of the step (statistics of the previous rollout, rollout,
+        # GAE) carry a start/stop event pair, and the GAE launch's pair is what `roofline` reports.  A pair on the GAE
+        # launch ALONE, right behind an un-timed rollout kernel, reads 1-2 us longer than the same dispatch under
+        # rocprofv3 --kernel-trace (rounds 2-3 measured it that way: 20.9-22.6 us against the trace's 20.3); with its
+        # neighbours timestamped too the two agree (20.3-20.7 us).  A pair costs ~5.7 us of the step it sits in, so
+        # K = 8 (six sampled steps in 50, ~2 us per step on average) -- `value` includes that cost.
         step_no[0] += 1
         record = record and args.gae_event_every > 0 and step_no[0] % args.gae_event_every == 0
+        record = record and SAMPLE_SLOTS * (len(gae_events) + 1) <= 128       # event slots 0..127 (128.. are the step breakdown's)
+        if record:
+            _lib.check(lib.ppo_prof_arm(SAMPLE_SLOTS * len(gae_events), SAMPLE_SLOTS), "ppo_prof_arm")
         ve.rollout()
         with torch.no_grad():
             if ve._ev_ready:                       # whole-rollout kernel wrote V(terminal obs) itself
                 ev_dense = ve._ev_dense
             else:
                 ev_dense = ppo._scatter_end_values(ve, agent.get_values(ve.end_states))
-            record = record and len(gae_events) < 128   # event slots 0..127 (128.. are the step breakdown's)
-            # hipExtLaunchKernelGGL start/stop events on the GAE dispatch itself (ppo_gae_dense_timed in
-            # csrc/gae.hip); read back after the timed region.  Agrees with rocprofv3 --kernel-trace.
-            slot = len(gae_events) if record else None
             if ve._ev_ready:                       # ... and the packed flag bits: the trainer's path (PPO._rollout_advantages)
-                adv = ops.gae_dense_packed(ve.rewards, ve.values, ev_dense, ve._flag_words, 0.99, 0.95, prof_slot=slot)
+                adv = ops.gae_dense_packed(ve.rewards, ve.values, ev_dense, ve._flag_words, 0.99, 0.95)
             else:
-                adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95,
-                                    prof_slot=slot)
-            if record:
-                gae_events.append(slot)
+                adv = ops.gae_dense(ve.rewards, ve.values, ev_dense, ve.done_flags, ve.trunc_flags, 0.99, 0.95)
+            if record:                             # GAE is the step's last launch: its events sit in the last slot taken
+                gae_events.append(lib.ppo_prof_next() - 1)
+                _lib.check(lib.ppo_prof_arm(0, 0), "ppo_prof_arm")
         return adv
 
     def barrier():
@@ -418,10 +422,9 @@ def main():
             "roofline": {"kernel": "k_gae_words (ppo_gae_dense_packed)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-                         "avg_launch_us": gae_ms * 1e3, "algorithmic_bytes_per_launch": gae_bytes,
-                         # the same kernel in the twelve fully instrumented steps behind the timed region (every launch of
-                         # the step timestamped, as under rocprofv3 --kernel-trace, whose mean this one matches): a GAE
-                         # launch timed ALONE right behind the un-timed rollout kernel reads 1-2 us longer
+                         "avg_launch_us": gae_ms * 1e3, "n_samples": len(gae_us), "algorithmic_bytes_per_launch": gae_bytes,
+                         # the same kernel in the twelve instrumented steps BEHIND the timed region (step_breakdown_us);
+                         # avg_launch_us above is from the sampled steps INSIDE it (hot_path_step), n_samples of them
                          "avg_launch_us_instrumented_steps": float(gae_bd_us),
                          "frac_instrumented_steps": gae_bytes / (float(gae_bd_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "achieved_at_api_20B_per_elem": 20 * T * N / (gae_ms * 1e-3) / 1e9,

@@ -67,6 +67,7 @@ _PRIVATE = {
     "ppo_gae_dense_packed_variant": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_gae_dense_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _vp]),
     "ppo_prof_arm": (_i, [_i, _i]),
+    "ppo_prof_next": (_i, []),
     "ppo_test_acrobot_terminal": (_i, [_vp, _vp, _vp, _l, _vp]),
     "ppo_test_acrobot_quot": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
     "ppo_prof_elapsed_us": (_i, [_i, C.POINTER(C.c_float)]),

@@ -980,6 +980,10 @@ int ppo_prof_arm(int first_slot, int count)
     return 0;
 }
 
+// Slot the next armed launch would use (= first_slot + launches timed since ppo_prof_arm): tells a caller that armed a
+// whole step which slot its last launch landed in
+int ppo_prof_next(void) { return g_ppo_prof.next; }
+
 // ppo_gae_dense whose dispatch is timed into event slot `slot`
 int ppo_gae_dense_timed(const float *rewards, const float *values, const float *end_value_dense,
                         const int *done, const int *trunc, double gamma, double lam, float *adv,
