@@ -215,6 +215,7 @@ constexpr int ROLLOUT_BLOCK = 256;  // 4 waves, one per SIMD
 template <int OBS_, int A_, bool JOINT_> struct NetF32 {
     static constexpr int OBS = OBS_, A = A_, WAVE_ENVS = 64;
     static constexpr bool JOINT = JOINT_, DIFF = false;
+    static constexpr bool FULL_OK = false;         // (k_rollout's FULL form: the yardstick mode keeps its one form)
     static constexpr int NB = backbone_floats(OBS);
     static constexpr int S1 = ksteps(OBS), S2 = ksteps(H);
     static constexpr int LDS_WORDS = JOINT ? 1 : NB;
@@ -506,6 +507,11 @@ template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     static constexpr int OBS = OBS_, A = A_, WAVE_ENVS = 32 * ETILES_;
     static constexpr int BB16_WORDS = bb16_words(S::P), BB16_B2 = ppo_net::BB16_B2;
     static constexpr bool JOINT = JOINT_;
+    // k_rollout's FULL form (one scheduling region per step) only for the two-piece scheme: it gains 2.4 % there and
+    // 0.3 % with three pieces, and the three-piece split-net CartPole kernel compiled that way returns NaN log-probs for
+    // backbone weights from 0.5x the initialisation scale up (tests/test_gpu_net_precision.py caught it; every other
+    // FULL kernel passes the same sweep) -- hipcc 7.2 under the register pressure of that kernel, not chased
+    static constexpr bool FULL_OK = S::P == 2 && ETILES_ == 2;
     // Two actions: only l1 - l0 matters to softmax, log-probs and the sampled action, so the head
     // table holds the difference row (and bias) in slot 0 -- one policy dot product instead of two;
     // forward() then returns out[0] = l1 - l0 (bias4[0] = b1 - b0).
@@ -555,7 +561,14 @@ template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     }
 };
 
-template <class Env, class Net, bool DRAWS>
+// FULL: every lane of every wave of the grid owns an env (64-env waves, N a multiple of the 256 envs of a workgroup -- the
+// large batches this kernel is for).
+// `live` is then a compile-time true, and with it goes the exec-masked region around the env transition and the
+// stores: the step becomes ONE scheduling region, in which hipcc moves the part of the transition that does not depend
+// on the action (the pole angle's sin / cos, the products of the old state) up beside the network's MFMA chains
+// instead of starting it after the last head FMA.  A/B at C2, alternating fresh processes: 427.5 -> 417.2 us per
+// rollout (f16-split), 601.6 -> 599.6 us (bf16x3).  Same instructions per lane, bit-identical results.
+template <class Env, class Net, bool DRAWS, bool FULL = false>
 __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const float *__restrict__ params)
 {
     constexpr int OBS = Env::OBS, A = Net::A;
@@ -572,7 +585,8 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     const size_t n = wave * WE + (WE == 64 ? lane : (lane & 31));
     // Lanes without an env of their own (n >= N, or the upper half of a 32-env wave) stay: MFMA needs
     // all 64 lanes.  They shadow a valid env and never store.
-    const bool live = n < (size_t)a.env.N && (WE == 64 || lane < 32);
+    static_assert(!FULL || WE == 64, "FULL: 64-env waves");
+    const bool live = FULL || (n < (size_t)a.env.N && (WE == 64 || lane < 32));
     const size_t nn = n < (size_t)a.env.N ? n : (size_t)a.env.N - 1;
 
     __shared__ __attribute__((aligned(16))) float smem[Net::LDS_WORDS];
@@ -712,8 +726,15 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
 
 template <class Env, class Net> void launch_net(const RolloutArgs &a, unsigned grid, hipStream_t s)
 {
-    if (a.env.reset_draw) PPO_LAUNCH((k_rollout<Env, Net, true>), dim3(grid), dim3(ROLLOUT_BLOCK), s, a, a.params);
-    else PPO_LAUNCH((k_rollout<Env, Net, false>), dim3(grid), dim3(ROLLOUT_BLOCK), s, a, a.params);
+    if (a.env.reset_draw) {
+        PPO_LAUNCH((k_rollout<Env, Net, true>), dim3(grid), dim3(ROLLOUT_BLOCK), s, a, a.params);
+    } else if constexpr (Net::FULL_OK) {
+        // (every wave of the GRID must be full: N a multiple of the envs per workgroup, not just per wave)
+        if (a.env.N % ROLLOUT_BLOCK == 0) PPO_LAUNCH((k_rollout<Env, Net, false, true>), dim3(grid), dim3(ROLLOUT_BLOCK), s, a, a.params);
+        else PPO_LAUNCH((k_rollout<Env, Net, false>), dim3(grid), dim3(ROLLOUT_BLOCK), s, a, a.params);
+    } else {
+        PPO_LAUNCH((k_rollout<Env, Net, false>), dim3(grid), dim3(ROLLOUT_BLOCK), s, a, a.params);
+    }
 }
 
 // Envs per wave for the f16-split nets: 64, or 32 when the batch is too small to give every SIMD of
