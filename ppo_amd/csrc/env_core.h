@@ -58,9 +58,25 @@ __device__ __forceinline__ double div_by_total_mass(double x)
 // ---- CartPole-v1 ---------------------------------------------------------------------
 struct CartPole {
     static constexpr int OBS = 4;
-    struct Aux {};                                 // nothing derived from the state is worth carrying
+    // The pole angle of a state that a transition left behind is inside the termination band (an episode that ends is
+    // reset in the same transition), where sincos_small holds; only a state the CALLER wrote can lie outside it, and
+    // only the first step after a load can meet one.  So the general sin / cos is computed where the state is loaded
+    // (prime) and the step itself has no branch -- in the whole-rollout kernel a branch there splits the step's
+    // scheduling region between the network and the physics (415 -> 411 us per C2 rollout without it).
+    struct Aux {
+        bool wide;                                 // wave-uniform: some lane's loaded angle is outside sincos_small's range
+        double sn, cs;                             // sin / cos of the loaded angle, valid while `wide`
+    };
     static constexpr bool PAIR_TRIG = false;       // (see Acrobot)
-    template <bool PAIR = false> __device__ static void prime(const double (&)[4], Aux &) {}
+    template <bool PAIR = false> __device__ static void prime(const double (&s)[4], Aux &aux)
+    {
+        aux.wide = !__all(fabs(s[2]) < 0.3);
+        aux.sn = aux.cs = 0.0;
+        if (aux.wide) {                            // an env stepped past its terminal state by the caller
+            aux.cs = cos(s[2]);
+            aux.sn = sin(s[2]);
+        }
+    }
 
     template <bool PAIR = false>
     __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &)
@@ -74,7 +90,7 @@ struct CartPole {
 
     // returns terminated; reward is always 1.0
     template <bool PAIR = false>
-    __device__ static bool step(double (&s)[4], Aux &, int action, float (&obs)[6], float &reward)
+    __device__ static bool step(double (&s)[4], Aux &aux, int action, float (&obs)[6], float &reward)
     {
         constexpr double gravity = 9.8, masscart = 1.0, masspole = 0.1;
         constexpr double total_mass = masspole + masscart;
@@ -87,12 +103,10 @@ struct CartPole {
         double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const double force = (action == 1) ? force_mag : -force_mag;
         double costheta, sintheta;
-        if (__all(fabs(theta) < 0.3)) {               // wave-uniform: always true inside a rollout
-            sincos_small(theta, sintheta, costheta);
-        } else {                                      // an env stepped past its terminal state by the caller
-            costheta = cos(theta);
-            sintheta = sin(theta);
-        }
+        sincos_small(theta, sintheta, costheta);
+        sintheta = aux.wide ? aux.sn : sintheta;      // (first step after a load only, see Aux)
+        costheta = aux.wide ? aux.cs : costheta;
+        aux.wide = false;
         static_assert(total_mass == 1.1, "div_by_total_mass divides by 1.1");
         const double temp = div_by_total_mass(force + polemass_length * (theta_dot * theta_dot) * sintheta);
         const double thetaacc = (gravity * sintheta - costheta * temp) /

@@ -106,6 +106,50 @@ def test_single_step_from_identical_states(kind, na):
           f"max rel err {err.max():.2e}")
 
 
+def test_cartpole_step_from_a_state_past_the_termination_band():
+    """A pole angle that no transition leaves behind (|theta| up to 3 rad; gymnasium only warns when an env is stepped
+    past its terminal state): the kernels take the general sin / cos for the step after the load
+    (csrc/env_core.h CartPole::Aux).  Per-step kernel and the whole-rollout kernel's first step, whole waves of
+    such states and waves where only some lanes hold one."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    N = 4096
+    rng = np.random.default_rng(7)
+    dev, ora = DevBatch("cartpole", N, seed=5), cref.BatchEnv("cartpole", N, seed=5)
+    dev.reset(); ora.reset()
+    st = rng.uniform(-1, 1, (N, 4)) * [1.0, 2.0, 3.0, 2.0]
+    st[1024:, 2] *= 0.05                             # waves inside the band
+    st[2048::97, 2] = 1.7                            # single lanes outside it
+    ora.state[:] = st
+    sync_state(dev, ora)
+    a = rng.integers(0, 2, N)
+    u = rng.random((N, 4))
+    o_d, t_d, r_d, d_d, tr_d = dev.step(a, reset_draw=u)
+    o_c, t_c, r_c, d_c, tr_c = ora.step(a, reset_draw=u)
+    assert np.array_equal(d_d, d_c) and np.array_equal(tr_d, tr_c) and 900 < d_c.sum() < N
+    assert np.allclose(t_d, t_c, rtol=RTOL, atol=1e-7) and np.allclose(o_d, o_c, rtol=RTOL, atol=1e-7)
+    assert np.abs(dev.b.state.cpu().numpy() - ora.state).max() < 1e-14
+
+    # the whole-rollout kernel: same states, its own sampled actions replayed through the oracle for one step
+    torch.manual_seed(0)
+    probe = DeviceEnv("cartpole")
+    agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
+    for n_envs in (N, 1000):                         # the form without the per-lane branch, and the general one
+        ve = SyncVecEnv(lambda: DeviceEnv("cartpole", seed=5), n_envs, 4, 0, 0.0, agent, seed=5)
+        ve.wave_envs = 64
+        ora = cref.BatchEnv("cartpole", n_envs, seed=5)
+        ora.reset()
+        ora.state[:] = st[:n_envs]
+        ve.batch.state.copy_(torch.from_numpy(ora.state))
+        ve.t_states.copy_(torch.from_numpy(ora.state.astype(np.float32)))
+        ve.rollout()
+        o_c, t_c, r_c, d_c, tr_c = ora.step(ve.actions[0].cpu().numpy())
+        assert np.array_equal(ve.done_flags[0].cpu().numpy(), d_c) and d_c.sum() > 200
+        assert np.allclose(ve.states[1].detach().cpu().numpy(), o_c, rtol=RTOL, atol=1e-7)
+        ended = torch.from_numpy(d_c > 0)
+        assert np.allclose(ve._term_obs[0].cpu()[ended].numpy(), t_c[d_c > 0], rtol=RTOL, atol=1e-7)
+
+
 @pytest.mark.parametrize("kind,na,steps", [("cartpole", 2, 1100), ("acrobot", 3, 1100)])
 def test_trajectories_flags_and_episode_lengths_bit_exact(kind, na, steps):
     """2048 envs x 1100 steps along realistic trajectories (random policy + a balancing controller on

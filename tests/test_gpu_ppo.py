@@ -402,6 +402,34 @@ def test_rollout_is_bit_identical_for_both_wave_widths(kind, joint, request):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kind,joint", [("cartpole", 0), ("cartpole", 1), ("acrobot", 0), ("acrobot", 1)])
+def test_rollout_full_form_matches_the_general_form(kind, joint, request):
+    """A batch whose 64-env waves are all full (N a multiple of the 256-env workgroup) runs k_rollout's FULL form, which
+    has no per-lane `live` branch (csrc/rollout.hip launch_net); any other N runs the general form.  An env's stream
+    depends on its index and the seed only, so the first 500 envs of a 512-env batch and a 500-env batch must agree
+    bit for bit in every rollout buffer, over two rollouts (the second starts from carried state)."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    torch.manual_seed(5)
+    probe = DeviceEnv(kind)
+    agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
+    with torch.no_grad():
+        agent.policy.weight.mul_(40.0)
+    got = {}
+    for N in (512, 500):
+        ve = SyncVecEnv(lambda: DeviceEnv(kind, seed=13), N, 64, 0, 0.0, agent, seed=13)
+        ve.wave_envs = 64
+        ve.rollout(); ve.rollout()
+        got[N] = [getattr(ve, k).detach()[:, :500].clone() for k in
+                  ("states", "actions", "log_probs", "values", "rewards", "done_flags", "trunc_flags")]
+        got[N].append(ve.t_states[:500].clone())
+        es = ve.end_states                           # actor-major list of terminal observations
+        got[N].append(es[ve._end_n < 500].clone())
+    assert int(got[512][5].sum()) > 0 or kind == "acrobot"   # CartPole episodes ended inside the window
+    for a, b in zip(got[512], got[500]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("ring,N", [(1, 300), (7, 1000), (63, 129), (64, 64), (65, 500), (100, 70), (130, 257), (257, 33)])
 def test_episode_statistics_any_ring_length(ring, N):
     """ppo_episode_stats through the C ABI for ring lengths other than the 100 SyncVecEnv uses (the
