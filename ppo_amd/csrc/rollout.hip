@@ -507,11 +507,15 @@ template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
     static constexpr int OBS = OBS_, A = A_, WAVE_ENVS = 32 * ETILES_;
     static constexpr int BB16_WORDS = bb16_words(S::P), BB16_B2 = ppo_net::BB16_B2;
     static constexpr bool JOINT = JOINT_;
-    // k_rollout's FULL form (one scheduling region per step) only for the two-piece scheme: it gains 2.4 % there and
-    // 0.3 % with three pieces, and the three-piece split-net CartPole kernel compiled that way returns NaN log-probs for
-    // backbone weights from 0.5x the initialisation scale up (tests/test_gpu_net_precision.py caught it; every other
-    // FULL kernel passes the same sweep) -- hipcc 7.2 under the register pressure of that kernel, not chased
+    // k_rollout's FULL form (one scheduling region per step) only for the two-piece scheme, where it gains 2.4 %; with
+    // three pieces it gains 0.3 %, not worth a third instantiation per env.  (The first FULL build of the three-piece
+    // split-net CartPole kernel also returned NaN log-probs in a few waves per launch: hipcc 7.2 lost the fourth dword of
+    // a spilled weight fragment -- tools/check_spills.py, run by the Makefile on every build since, and DESIGN.md 4.2.)
+#ifdef PPO_ROLLOUT_FULL_ALL                        // (development: tools/build_variant.sh x -DPPO_ROLLOUT_FULL_ALL)
+    static constexpr bool FULL_OK = ETILES_ == 2;
+#else
     static constexpr bool FULL_OK = S::P == 2 && ETILES_ == 2;
+#endif
     // Two actions: only l1 - l0 matters to softmax, log-probs and the sampled action, so the head
     // table holds the difference row (and bias) in slot 0 -- one policy dot product instead of two;
     // forward() then returns out[0] = l1 - l0 (bias4[0] = b1 - b0).

@@ -6,7 +6,9 @@ name=$1; shift
 cd "$(dirname "$0")/../ppo_amd/csrc"
 mkdir -p ../../variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
-    -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c rollout.hip -o ../../variants/rollout_$name.o
+    -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -save-temps=obj -c rollout.hip -o ../../variants/rollout_$name.o
+python3 ../../tools/check_spills.py ../../variants/rollout_$name-hip-amdgcn-amd-amdhsa-gfx950.s || echo "check_spills: FINDINGS in variant $name (see above)"
+rm -f ../../variants/rollout_$name-h* ../../variants/rollout_$name.hip-hip-*
 objs=$(ls *.o | grep -v '^rollout.o$')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib$name.so $objs ../../variants/rollout_$name.o
 echo "built variants/lib$name.so"
