@@ -45,8 +45,13 @@ template <class Env> __global__ void __launch_bounds__(256) k_env_step(EnvArgs a
     load_env(e, a, n);
     StepOut o;
     typename Env::Aux aux;
-    Env::prime(e.s, aux);
-    env_transition<Env>(e, aux, a.action[n], a, n, a.is_last, o);
+    if (Env::TWO_FORMS && Env::wide(e.s)) {        // a caller-written state outside what a transition leaves (env_core.h)
+        Env::template prime<false, true>(e.s, aux);
+        env_transition<Env, true, false, true>(e, aux, a.action[n], a, n, a.is_last, o);
+    } else {
+        Env::prime(e.s, aux);
+        env_transition<Env>(e, aux, a.action[n], a, n, a.is_last, o);
+    }
     a.reward[n] = o.reward;
     a.done[n] = o.done;
     a.trunc[n] = o.trunc;

@@ -42,6 +42,25 @@ __device__ __forceinline__ void sincos_small(double x, double &sn, double &cs)
     cs = 1.0 - (0.5 * z - z * rc);
 }
 
+// sin and cos for |x| < 1.6e6 (|n| < 2^20 quarter turns): Cody-Waite reduction with pi/2 in three pieces (33 + 33 + 53
+// bits, fdlibm's pio2_1 / pio2_2 / pio2_3: n pio2_1 and n pio2_2 are exact products, so the first step is exact and the
+// other two round once each, relative to their own result) and the fdlibm kernel polynomials on |r| <= pi/4: ~40
+// instructions and no branch, against ~70 and a large-argument branch (Payne-Hanek) in the device libm's sincos.
+// Acrobot's eight calls per step are what it is for (Acrobot::trig_of); NaN in, NaN out, like libm.
+__device__ __forceinline__ void sincos_bounded(double x, double &sn, double &cs)
+{
+    const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-fn, 6.07710050630396597660e-11, r);
+    r = __builtin_fma(-fn, 2.02226624871116645580e-21, r);
+    const int n = (int)fn;
+    double s, c;
+    sincos_small(r, s, c);
+    const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;         // quadrant: (s, c), (c, -s), (-s, -c), (-c, s)
+    sn = (n & 2) ? -a : a;
+    cs = ((n + 1) & 2) ? -b : b;
+}
+
 // x / 1.1 (CartPole's total_mass) as three FMAs instead of the ~12-instruction IEEE division sequence:
 // q = RN(x r), r = RN(1 / 1.1); the remainder x - 1.1 q is exact in an FMA; q' = RN(q + rem r) is the
 // correctly rounded quotient (Markstein's correction step with a correctly rounded reciprocal).
@@ -68,7 +87,9 @@ struct CartPole {
         double sn, cs;                             // sin / cos of the loaded angle, valid while `wide`
     };
     static constexpr bool PAIR_TRIG = false;       // (see Acrobot)
-    template <bool PAIR = false> __device__ static void prime(const double (&s)[4], Aux &aux)
+    static constexpr bool TWO_FORMS = false;       // (see Acrobot)
+    __device__ static __forceinline__ bool wide(const double (&)[4]) { return false; }
+    template <bool PAIR = false, bool GENERAL = false> __device__ static __forceinline__ void prime(const double (&s)[4], Aux &aux)
     {
         aux.wide = !__all(fabs(s[2]) < 0.3);
         aux.sn = aux.cs = 0.0;
@@ -79,7 +100,7 @@ struct CartPole {
     }
 
     template <bool PAIR = false>
-    __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &)
+    __device__ static __forceinline__ void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &)
     {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -89,8 +110,8 @@ struct CartPole {
     }
 
     // returns terminated; reward is always 1.0
-    template <bool PAIR = false>
-    __device__ static bool step(double (&s)[4], Aux &aux, int action, float (&obs)[6], float &reward)
+    template <bool PAIR = false, bool GENERAL = false>
+    __device__ static __forceinline__ bool step(double (&s)[4], Aux &aux, int action, float (&obs)[6], float &reward)
     {
         constexpr double gravity = 9.8, masscart = 1.0, masspole = 0.1;
         constexpr double total_mass = masspole + masscart;
@@ -147,20 +168,43 @@ struct Acrobot {
     // exchange the results.  One sincos per pair instead of two with all 64 lanes busy, 4 instead of 8 per step; the
     // function values are the same whichever lane computes them, so results are bit-identical to the unpaired form.
     // Every call site is reached by both lanes of a pair or by neither (they hold identical state).
+    //
+    // TWO_FORMS.  The calls are sincos_bounded, not libm's sincos: a state that a transition or a reset left behind has
+    // |theta| <= pi, |w1| <= 4 pi, |w2| <= 9 pi (wrap and clip at the end of step()), and from such a state no RK4 stage
+    // angle exceeds ~3.4e3 rad.  (With W = max |w|: |phi1| <= 1.5 W^2 + 19.6, |phi2| <= 4.9, d1 in [2.5, 4.5], d2 in
+    // [0.75, 1.75], den in [0.57, 1.03], so both accelerations are below A(W) = 2.72 W^2 + 35; stage velocities
+    // W1 <= 28.3 + 0.1 A(28.3) = 250, W2 <= 28.3 + 0.1 A(250) = 1.7e4, and the last stage's angles are
+    // theta + 0.2 W2 <= 3.4e3 -- three orders inside sincos_bounded's range.)  Only a state the CALLER wrote can lie
+    // outside those bounds; a wave that loads one (wide(), wave-uniform) runs the GENERAL form of the transition,
+    // which calls libm: the whole-rollout kernel holds its step loop twice and picks one per wave at entry, so the
+    // loop everybody runs carries neither the check nor the slow path.  Acrobot rollout kernel at N = 65 536, T = 128:
+    // 688 -> 628 us (profiles/r03_last_session_ab.txt).
     struct Trig { double s1, c1, s2, c2; };
     using Aux = Trig;
     static constexpr bool PAIR_TRIG = true;
-    template <bool PAIR = false> __device__ static void prime(const double (&s)[4], Aux &aux) { aux = trig_of<PAIR>(s[0], s[1]); }
-    template <bool PAIR = false> __device__ static Trig trig_of(double theta1, double theta2)
+    static constexpr bool TWO_FORMS = true;
+    __device__ static __forceinline__ bool wide(const double (&s)[4])
+    {
+        return !__all(fabs(s[0]) <= PI && fabs(s[1]) <= PI && fabs(s[2]) <= 4 * PI && fabs(s[3]) <= 9 * PI);
+    }
+    template <bool GENERAL> __device__ static __forceinline__ void sincos_of(double x, double &sn, double &cs)
+    {
+        if constexpr (GENERAL) sincos(x, &sn, &cs); else sincos_bounded(x, sn, cs);
+    }
+    template <bool PAIR = false, bool GENERAL = false> __device__ static __forceinline__ void prime(const double (&s)[4], Aux &aux)
+    {
+        aux = trig_of<PAIR, GENERAL>(s[0], s[1]);
+    }
+    template <bool PAIR = false, bool GENERAL = false> __device__ static __forceinline__ Trig trig_of(double theta1, double theta2)
     {
         Trig t;
         if constexpr (!PAIR) {
-            sincos(theta1, &t.s1, &t.c1);
-            sincos(theta2, &t.s2, &t.c2);
+            sincos_of<GENERAL>(theta1, t.s1, t.c1);
+            sincos_of<GENERAL>(theta2, t.s2, t.c2);
         } else {
             const bool upper = (threadIdx.x & 32u) != 0u;
             double sn, cs;
-            sincos(upper ? theta2 : theta1, &sn, &cs);
+            sincos_of<GENERAL>(upper ? theta2 : theta1, sn, cs);
             const double so = __shfl_xor(sn, 32, 64), co = __shfl_xor(cs, 32, 64);   // the partner lane's angle
             t.s1 = upper ? so : sn; t.c1 = upper ? co : cs;
             t.s2 = upper ? sn : so; t.c2 = upper ? cs : co;
@@ -168,9 +212,9 @@ struct Acrobot {
         return t;
     }
 
-    template <bool PAIR = false> __device__ static Trig write_obs(const double (&s)[4], float (&obs)[6])
+    template <bool PAIR = false, bool GENERAL = false> __device__ static __forceinline__ Trig write_obs(const double (&s)[4], float (&obs)[6])
     {
-        const Trig t = trig_of<PAIR>(s[0], s[1]);
+        const Trig t = trig_of<PAIR, GENERAL>(s[0], s[1]);
         obs[0] = (float)t.c1; obs[1] = (float)t.s1;
         obs[2] = (float)t.c2; obs[3] = (float)t.s2;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
@@ -178,7 +222,7 @@ struct Acrobot {
     }
 
     template <bool PAIR = false>
-    __device__ static void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &aux)
+    __device__ static __forceinline__ void reset(double (&s)[4], const double (&u)[4], float (&obs)[6], Aux &aux)
     {
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] = (double)(float)(-0.1 + (0.1 - -0.1) * u[k]);  // .astype(float32)
@@ -190,20 +234,20 @@ struct Acrobot {
     // scaling and fix-up instructions of the general IEEE sequence.  quot() then rounds n / d like the
     // division does (Markstein's correction with the refined reciprocal): a stage's four divisions,
     // three of them by d1, cost two reciprocals and four 3-instruction quotients.
-    __device__ static double recip(double d)
+    __device__ static __forceinline__ double recip(double d)
     {
         double r = __builtin_amdgcn_rcp(d);
         r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
         r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
         return r;
     }
-    __device__ static double quot(double n, double d, double r)
+    __device__ static __forceinline__ double quot(double n, double d, double r)
     {
         const double q = n * r;
         return __builtin_fma(__builtin_fma(-q, d, n), r, q);
     }
 
-    __device__ static void dsdt(const double (&y)[4], const Trig &t, double a, double (&out)[4])
+    __device__ static __forceinline__ void dsdt(const double (&y)[4], const Trig &t, double a, double (&out)[4])
     {
         const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
         const double dtheta1 = y[2], dtheta2 = y[3];
@@ -223,7 +267,7 @@ struct Acrobot {
         out[0] = dtheta1; out[1] = dtheta2; out[2] = ddtheta1; out[3] = ddtheta2;
     }
 
-    __device__ static double wrap(double x, double m, double M)
+    __device__ static __forceinline__ double wrap(double x, double m, double M)
     {
         const double diff = M - m;
         while (x > M) x = x - diff;
@@ -231,8 +275,8 @@ struct Acrobot {
         return x;
     }
 
-    template <bool PAIR = false>
-    __device__ static bool step(double (&s)[4], Aux &aux, int action, float (&obs)[6], float &reward)
+    template <bool PAIR = false, bool GENERAL = false>
+    __device__ static __forceinline__ bool step(double (&s)[4], Aux &aux, int action, float (&obs)[6], float &reward)
     {
         const double dt = 0.2 - 0;
         const double dt2 = dt / 2.0;
@@ -241,13 +285,13 @@ struct Acrobot {
         dsdt(s, aux, torque, k1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k1[i];
-        dsdt(y, trig_of<PAIR>(y[0], y[1]), torque, k2);
+        dsdt(y, trig_of<PAIR, GENERAL>(y[0], y[1]), torque, k2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k2[i];
-        dsdt(y, trig_of<PAIR>(y[0], y[1]), torque, k3);
+        dsdt(y, trig_of<PAIR, GENERAL>(y[0], y[1]), torque, k3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = s[i] + dt * k3[i];
-        dsdt(y, trig_of<PAIR>(y[0], y[1]), torque, k4);
+        dsdt(y, trig_of<PAIR, GENERAL>(y[0], y[1]), torque, k4);
         double ns[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) ns[i] = s[i] + dt / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
@@ -257,7 +301,7 @@ struct Acrobot {
         ns[3] = fmin(fmax(ns[3], -9 * PI), 9 * PI);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = ns[i];
-        const Trig t = aux = write_obs<PAIR>(s, obs);
+        const Trig t = aux = write_obs<PAIR, GENERAL>(s, obs);
         const bool terminated = terminal(s, t);
         reward = terminated ? 0.0f : -1.0f;
         return terminated;
@@ -267,17 +311,17 @@ struct Acrobot {
     // observation's own sin / cos (angle-sum identity) saves a trigonometric reduction per step and agrees with
     // the direct value to a few 1e-16 -- so the identity DECIDES only where it cannot be wrong: outside a band of
     // 1e-9 around the threshold, a million times its worst-case error.  Inside the band the reference's own
-    // expression is evaluated -- cos(theta1 + theta2) of the summed angle; t.c1 IS cos(s[0]), the library's sincos
-    // and cos share reduction and polynomial -- so the flag is, structurally, that expression's (wave-uniform
+    // expression is evaluated with the library's cos -- of theta1 and of the summed angle -- so the flag is,
+    // structurally, that expression's (wave-uniform
     // branch; taken by about one step in 10^9).  Price, measured (profiles/r03_acrobot_guard_band_ab.txt): 8 us of
     // a 701 us rollout at N = 65536, T = 128 -- the branch splits a scheduling region; the cosine itself never runs.
-    __device__ static bool terminal(const double (&s)[4], const Trig &t)
+    __device__ static __forceinline__ bool terminal(const double (&s)[4], const Trig &t)
     {
         const double lhs = -t.c1 - __builtin_fma(t.c1, t.c2, -(t.s1 * t.s2));
         bool terminated = lhs > 1.0;
 #ifndef PPO_ACROBOT_NO_GUARD_BAND                     // (tools/build_variant.sh: the A/B build that prices the band)
         if (__any(fabs(lhs - 1.0) < 1e-9)) {
-            if (fabs(lhs - 1.0) < 1e-9) terminated = (-t.c1 - cos(s[1] + s[0]) > 1.0);
+            if (fabs(lhs - 1.0) < 1e-9) terminated = (-cos(s[0]) - cos(s[1] + s[0]) > 1.0);
         }
 #endif
         return terminated;
@@ -362,11 +406,11 @@ struct ResetAhead {
 // the actor loop of the reference's rollout (src/ppo.py:342-388).
 // PAIR: the caller runs this for BOTH lanes that carry env n in a 32-env wave (Acrobot::trig_of); `owner` is false in
 // the lane that only helps -- it keeps its copy of the env in step but writes nothing to memory.
-template <class Env, bool DRAWS = true, bool PAIR = false>
+template <class Env, bool DRAWS = true, bool PAIR = false, bool GENERAL = false>
 __device__ __forceinline__ void env_transition(EnvRegs &e, typename Env::Aux &aux, int action, const EnvArgs &a, size_t n, int is_last,
                                                StepOut &o, ResetAhead *ahead = nullptr, bool owner = true)
 {
-    const bool terminated = Env::template step<PAIR>(e.s, aux, action, o.obs, o.reward);
+    const bool terminated = Env::template step<PAIR, GENERAL>(e.s, aux, action, o.obs, o.reward);
     e.elapsed += 1;                                          // TimeLimit.step
     const bool truncated = e.elapsed >= MAX_EPISODE_STEPS;
     o.done = terminated ? 1 : 0;

@@ -33,6 +33,7 @@
 // Bound: VALU issue (f16 form: 1243 VALU instructions per wave and step, 70 % of the wave's cycles;
 // the f32 form is bound by its 144 x 64 MFMA cycles, which do not overlap with the wave's VALU
 // work).  HBM: 40 B written per env-step (states 16, action, log-prob, value, reward, done, trunc).
+#include <type_traits>
 #include "env_core.h"
 #include "net_layout.h"
 #include "mfma_split.h"
@@ -600,7 +601,11 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     EnvRegs e;
     load_env(e, a.env, nn);
     typename Env::Aux aux;                         // what the env derives from its state and carries along with it
-    Env::template prime<PAIR>(e.s, aux);
+    // an env with TWO_FORMS of its transition (Acrobot, env_core.h): a wave that loaded a state no transition leaves
+    // behind runs its FIRST step in the GENERAL form, ahead of the loop; the loop itself only holds the fast form
+    const bool general_form = Env::TWO_FORMS && __builtin_amdgcn_readfirstlane((int)Env::wide(e.s)) != 0;   // (uniform, and known to be)
+    if (general_form) Env::template prime<PAIR, true>(e.s, aux);
+    else Env::template prime<PAIR>(e.s, aux);
     ResetAhead ahead;
     float obs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -612,8 +617,11 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     // inside it: there it would also wait for the previous step's stores (vmcnt counts both).
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), other counters untouched
     int pend_t = -1;                               // row of this env's truncation still waiting for its bootstrap value
-    // Second network pass over the terminal observations of the envs with a pending truncation
-    auto settle = [&]() {
+    // Second network pass over the terminal observations of the envs with a pending truncation.  always_inline: given
+    // a third call site hipcc made it a real function, reached by s_swappc with the network's registers handed over
+    // through scratch -- and its upper half-wave came back with f16-grade values (tests/test_gpu_bench_shapes.py,
+    // Acrobot, while this kernel held two step loops); tools/check_spills.py now refuses calls inside a kernel
+    auto settle = [&]() __attribute__((always_inline)) {
         const bool has = pend_t >= 0;
         float tobs[6];
         __builtin_amdgcn_s_waitcnt(0x0F70);        // this wave's term_obs stores have landed (rare path)
@@ -631,7 +639,8 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     SampleDraws draws;
     draws.w0 = draws.w1 = draws.w2 = 0u;
     uint32_t flag_bits = 0u;
-    for (int t = 0; t < a.T; ++t) {
+    auto step_body = [&](auto general, const int t) __attribute__((always_inline)) {
+        constexpr bool GENERAL = decltype(general)::value;     // (only ever the rollout's first step: nothing is pending)
         StepOut o;
         o.trunc = 0;
         // the step's uniform draw first (see sample_uniform)
@@ -667,13 +676,13 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         if constexpr (PAIR) {                      // both lanes of a pair step their copy of the env, with ITS action
             action = __shfl(action, lane & 31, 64);
             if (!(ABLATE(a) & 2))
-                env_transition<Env, DRAWS, true>(e, aux, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead, live);
+                env_transition<Env, DRAWS, true, GENERAL>(e, aux, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead, live);
         }
         if (live) {
             if (PAIR && !(ABLATE(a) & 2)) {
                 // (stepped above)
             } else if (!(ABLATE(a) & 2)) {
-                env_transition<Env, DRAWS>(e, aux, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead);
+                env_transition<Env, DRAWS, false, GENERAL>(e, aux, action, a.env, nn, t == a.T - 1, o, DRAWS ? nullptr : &ahead);
             } else {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o.obs[k] = obs[k] + 1e-3f * (float)action;
@@ -710,13 +719,23 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         // truncation of the last row, for envs that also hit the time limit earlier) and once after
         // the loop: one or two passes per rollout instead of one on every step on which some env
         // of the wave reaches the 500-step limit (~1/8 of the steps for long episodes).
-        if (__any(pend_t >= 0 && need_ev)) settle();
+        if constexpr (!GENERAL) {
+            if (__any(pend_t >= 0 && need_ev)) settle();
+        }
         if (need_ev) pend_t = t;
         if (live) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) obs[k] = o.obs[k];
         }
+    };
+    int t0 = 0;
+    if constexpr (Env::TWO_FORMS) {
+        if (general_form) {                        // (T >= 1: ppo_rollout_fused returns before the launch otherwise)
+            step_body(std::true_type{}, 0);
+            t0 = 1;
+        }
     }
+    for (int t = t0; t < a.T; ++t) step_body(std::false_type{}, t);
     if (__any(pend_t >= 0)) settle();
     if (live) {
         store_env(e, a.env, n);

@@ -150,6 +150,54 @@ def test_cartpole_step_from_a_state_past_the_termination_band():
         assert np.allclose(ve._term_obs[0].cpu()[ended].numpy(), t_c[d_c > 0], rtol=RTOL, atol=1e-7)
 
 
+def test_acrobot_step_from_a_state_outside_the_clip_bounds():
+    """Angles beyond +-pi and velocities beyond the clip bounds -- states no transition leaves behind, only a caller can
+    write them: the kernels run the GENERAL form of the transition for such a wave (libm's sincos instead of the
+    bounded-range one, csrc/env_core.h Acrobot TWO_FORMS).  Per-step kernel and the whole-rollout kernel's first step;
+    waves made of such states, waves with single lanes of them, and plain waves beside them."""
+    from ppo_amd import Agent, SyncVecEnv
+    from ppo_amd.envs import DeviceEnv
+    N = 4096
+    rng = np.random.default_rng(9)
+    dev, ora = DevBatch("acrobot", N, seed=5), cref.BatchEnv("acrobot", N, seed=5)
+    dev.reset(); ora.reset()
+    st = rng.uniform(-1, 1, (N, 4)) * [np.pi, np.pi, 4 * np.pi, 9 * np.pi]
+    st[:1024] *= [40.0, 40.0, 3.0, 3.0]              # whole waves outside: angles to 125 rad, velocities to 3x the clip
+    st[2048::97, 3] = 100.0                          # single lanes outside
+    st[2048::89, 0] = -7.0
+    ora.state[:] = st
+    sync_state(dev, ora)
+    a = rng.integers(0, 3, N)
+    u = rng.random((N, 4))
+    o_d, t_d, r_d, d_d, tr_d = dev.step(a, reset_draw=u)
+    o_c, t_c, r_c, d_c, tr_c = ora.step(a, reset_draw=u)
+    assert np.array_equal(d_d, d_c) and np.array_equal(tr_d, tr_c) and d_c.sum() > 100
+    assert np.allclose(t_d, t_c, rtol=RTOL, atol=1e-7) and np.allclose(o_d, o_c, rtol=RTOL, atol=1e-7)
+    err = np.abs(dev.b.state.cpu().numpy() - ora.state) / np.maximum(np.abs(ora.state), 1.0)
+    assert err.max() < 1e-9, err.max()               # (stage accelerations of ~1e7 amplify an ulp of a stage's sin / cos)
+
+    torch.manual_seed(0)
+    probe = DeviceEnv("acrobot")
+    agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
+    for n_envs in (N, 1000):                         # 64-env waves without / with the per-lane branch
+        for width in (64, 32):
+            ve = SyncVecEnv(lambda: DeviceEnv("acrobot", seed=5), n_envs, 4, 0, 0.0, agent, seed=5)
+            ve.wave_envs = width
+            ora = cref.BatchEnv("acrobot", n_envs, seed=5)
+            ora.reset()
+            ora.state[:] = st[:n_envs]
+            ve.batch.state.copy_(torch.from_numpy(ora.state))
+            obs0 = np.stack([np.cos(st[:n_envs, 0]), np.sin(st[:n_envs, 0]), np.cos(st[:n_envs, 1]), np.sin(st[:n_envs, 1]),
+                             st[:n_envs, 2], st[:n_envs, 3]], 1).astype(np.float32)
+            ve.t_states.copy_(torch.from_numpy(obs0))
+            ve.rollout()
+            o_c, t_c, r_c, d_c, tr_c = ora.step(ve.actions[0].cpu().numpy())
+            assert np.array_equal(ve.done_flags[0].cpu().numpy(), d_c) and d_c.sum() > 20
+            assert np.allclose(ve.states[1].detach().cpu().numpy(), o_c, rtol=RTOL, atol=1e-7)
+            ended = torch.from_numpy(d_c > 0)
+            assert np.allclose(ve._term_obs[0].cpu()[ended].numpy(), t_c[d_c > 0], rtol=RTOL, atol=1e-7)
+
+
 @pytest.mark.parametrize("kind,na,steps", [("cartpole", 2, 1100), ("acrobot", 3, 1100)])
 def test_trajectories_flags_and_episode_lengths_bit_exact(kind, na, steps):
     """2048 envs x 1100 steps along realistic trajectories (random policy + a balancing controller on

@@ -12,7 +12,10 @@ had left in that register.  No test can be relied on to catch th
 
 Checks, per kernel:
   1. a register written by spill code (`; Reload Reuse` / `Folded Reload`) and never read afterwards;
-  2. a matrix-core instruction reading a register that nothing before it (in layout order) has written.
+  2. a matrix-core instruction reading a register that nothing before it (in layout order) has written;
+  3. a function call inside a kernel (s_swappc): every device function here is meant to be inlined -- when hipcc
+     outlined the rollout kernel's second network pass (a lambda with three call sites), the callee got the
+     register-resident network through scratch and returned wrong values for half the wave.
 usage: check_spills.py file.s [file.s ...]      exit status 1 on a finding."""
 import re
 import sys
@@ -58,6 +61,8 @@ def check_kernel(name, body):
     written, read = set(), set()
     spilled = {}                                   # register -> line of the spill code that wrote it
     for ln, raw, op, dests, srcs in instructions(body):
+        if op.startswith("s_swappc"):
+            findings.append(f"{name}: line {ln}: function call inside the kernel: {raw.strip()}")
         for s in srcs:
             for r in regs(s):
                 read.add(r)
