@@ -295,37 +295,68 @@ struct Acrobot {
         double ns[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) ns[i] = s[i] + dt / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
-        ns[0] = wrap(ns[0], -PI, PI);
-        ns[1] = wrap(ns[1], -PI, PI);
+        // wrap(): the first trip of each of the reference's two loops as selects -- all there is to do for |x| <= 3 pi;
+        // whatever is left (a lane still outside) is finished in the step's one rare branch below
+        ns[0] = wrap_once(ns[0]);
+        ns[1] = wrap_once(ns[1]);
+        const bool unwrapped = fabs(ns[0]) > PI || fabs(ns[1]) > PI;
         ns[2] = fmin(fmax(ns[2], -4 * PI), 4 * PI);
         ns[3] = fmin(fmax(ns[3], -9 * PI), 9 * PI);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = ns[i];
-        const Trig t = aux = write_obs<PAIR, GENERAL>(s, obs);
-        const bool terminated = terminal(s, t);
+        Trig t = aux = write_obs<PAIR, GENERAL>(s, obs);
+        // gymnasium's termination test, bool(-cos(s[0]) - cos(s[1] + s[0]) > 1.0).  cos(theta1 + theta2) from the
+        // observation's own sin / cos (angle-sum identity) saves a trigonometric reduction per step and agrees with
+        // the direct value to a few 1e-16 -- so the identity DECIDES only where it cannot be wrong: outside a band of
+        // 1e-9 around the threshold, a million times its worst-case error.  Inside the band the reference's own
+        // expression is evaluated with the library's cos -- of theta1 and of the summed angle -- so the flag is,
+        // structurally, that expression's.
+        // ONE rare branch per step (wave-uniform; about one step in 10^9 takes it inside a rollout) holds both that and
+        // the rest of a long wrap(): every such branch splits the step's scheduling region whether taken or not -- the
+        // band's cost 8 us of a 701 us rollout at N = 65536 (profiles/r03_acrobot_guard_band_ab.txt), wrap()'s four
+        // while loops 12 us of 626 (profiles/r03_last_session_ab.txt).
+        double lhs = term_lhs(t);
+        bool terminated = lhs > 1.0;
+        if (__any(unwrapped || in_band(lhs))) {
+            if (unwrapped) {                          // (both lanes of a PAIR hold the same state: they come here together)
+                s[0] = wrap(s[0], -PI, PI);
+                s[1] = wrap(s[1], -PI, PI);
+                t = aux = write_obs<PAIR, GENERAL>(s, obs);
+                lhs = term_lhs(t);
+                terminated = lhs > 1.0;
+            }
+            if (in_band(lhs)) terminated = terminal_exact(s);
+        }
         reward = terminated ? 0.0f : -1.0f;
         return terminated;
     }
-
-    // gymnasium's termination test, bool(-cos(s[0]) - cos(s[1] + s[0]) > 1.0).  cos(theta1 + theta2) from the
-    // observation's own sin / cos (angle-sum identity) saves a trigonometric reduction per step and agrees with
-    // the direct value to a few 1e-16 -- so the identity DECIDES only where it cannot be wrong: outside a band of
-    // 1e-9 around the threshold, a million times its worst-case error.  Inside the band the reference's own
-    // expression is evaluated with the library's cos -- of theta1 and of the summed angle -- so the flag is,
-    // structurally, that expression's (wave-uniform
-    // branch; taken by about one step in 10^9).  Price, measured (profiles/r03_acrobot_guard_band_ab.txt): 8 us of
-    // a 701 us rollout at N = 65536, T = 128 -- the branch splits a scheduling region; the cosine itself never runs.
+    __device__ static __forceinline__ double wrap_once(double x)
+    {
+        x = x > PI ? x - (PI - -PI) : x;
+        x = x < -PI ? x + (PI - -PI) : x;
+        return x;
+    }
+    __device__ static __forceinline__ double term_lhs(const Trig &t) { return -t.c1 - __builtin_fma(t.c1, t.c2, -(t.s1 * t.s2)); }
+    __device__ static __forceinline__ bool in_band(double lhs)
+    {
+#ifndef PPO_ACROBOT_NO_GUARD_BAND                     // (tools/build_variant.sh: the A/B build that prices the band)
+        return fabs(lhs - 1.0) < 1e-9;
+#else
+        return false;
+#endif
+    }
+    __device__ static __forceinline__ bool terminal_exact(const double (&s)[4]) { return -cos(s[0]) - cos(s[1] + s[0]) > 1.0; }
+    // the decision on its own, as step() takes it (test hook k_test_acrobot_terminal)
     __device__ static __forceinline__ bool terminal(const double (&s)[4], const Trig &t)
     {
-        const double lhs = -t.c1 - __builtin_fma(t.c1, t.c2, -(t.s1 * t.s2));
+        const double lhs = term_lhs(t);
         bool terminated = lhs > 1.0;
-#ifndef PPO_ACROBOT_NO_GUARD_BAND                     // (tools/build_variant.sh: the A/B build that prices the band)
-        if (__any(fabs(lhs - 1.0) < 1e-9)) {
-            if (fabs(lhs - 1.0) < 1e-9) terminated = (-cos(s[0]) - cos(s[1] + s[0]) > 1.0);
+        if (__any(in_band(lhs))) {
+            if (in_band(lhs)) terminated = terminal_exact(s);
         }
-#endif
         return terminated;
     }
+
 };
 
 // Streaming variant: non-temporal stores for rollout buffers that nothing on the device reads again

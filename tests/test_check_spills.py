@@ -46,6 +46,14 @@ def test_complete_reload_passes(tmp_path):
     assert kernels == 1 and findings == []
 
 
+def test_a_call_inside_a_kernel_is_reported(tmp_path):
+    """hipcc outlined a lambda of the rollout kernel once (three call sites): the callee returned wrong values"""
+    text = WHOLE.replace("\ts_waitcnt vmcnt(0)\n\tv_mfma", "\ts_getpc_b64 s[0:1]\n\ts_swappc_b64 s[30:31], s[0:1]\n\ts_waitcnt vmcnt(0)\n\tv_mfma")
+    assert "s_swappc" in text
+    kernels, findings = _run(tmp_path, text)
+    assert kernels == 1 and len(findings) == 1 and "function call inside the kernel" in findings[0]
+
+
 def test_build_runs_the_check():
     mk = open(os.path.join(ROOT, "ppo_amd", "csrc", "Makefile")).read()
     assert "check_spills.py" in mk and "-save-temps=obj" in mk and ".DELETE_ON_ERROR" in mk
