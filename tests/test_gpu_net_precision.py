@@ -163,3 +163,32 @@ def test_network_error_vs_float64_over_scales(kind, joint):
             assert row["bf16x3_v_rms"] <= 1.25 * row["f32_v_rms"] + 2.0 ** -26, row
             assert row["bf16x3_v"] <= 1.5 * row["f32_v"] + ulp1_v, row
             assert row["bf16x3_lp"] <= 1.5 * row["f32_lp"] + 2.0 ** -24 * max(float(lp64a.abs().max()), 1.0), row
+
+
+@pytest.mark.parametrize("joint", [1, 0], ids=["joint", "split"])
+@pytest.mark.parametrize("kind", ["cartpole", "acrobot"])
+def test_no_nonfinite_outputs_whatever_ran_before(kind, joint):
+    """Every rollout kernel, 8 launches each, with a float64 PyTorch forward between the launches.  A development build
+    of one of these kernels once read a register that hipcc's spill code had not restored: harmless
+    unless the register's leftover bits -- those of the kernel that ran before -- read as Inf / NaN, and then whole
+    waves of NaN log-probs, 2-7 per launch, only among the first wave on each SIMD.  tools/check_spills.py looks for
+    the cause in the assembly at build time; this looks for the symptom (tools/soak_nan.py is the long form)."""
+    from ppo_amd import Agent, ops
+    from ppo_amd.envs import DeviceEnv
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    states = _states(kind, NSTATES, gen)
+    probe = DeviceEnv(kind)
+    torch.manual_seed(10001)
+    agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
+    with torch.no_grad():
+        for bb in [agent.pi_backbone] + ([] if joint else [agent.va_backbone]):
+            for lin in (bb[0], bb[2]):
+                lin.weight.mul_(4.0)
+    zero_act = torch.zeros(NSTATES, dtype=torch.int32, device="cuda")
+    for mode in (ops.NET_F16_SPLIT, ops.NET_BF16X3, ops.NET_F32):
+        bad = 0
+        for _ in range(8):
+            _f64(agent, states, zero_act)
+            v, act, lp, _ = _kernel_forward(kind, agent, states, mode)
+            bad += int((~(torch.isfinite(lp) & torch.isfinite(v))).sum())
+        assert bad == 0, (ops.NET_NAMES[mode], bad)
