@@ -53,6 +53,10 @@ __device__ __forceinline__ void sincos_bounded(double x, double &sn, double &cs)
     double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);
     r = __builtin_fma(-fn, 6.07710050630396597660e-11, r);
     r = __builtin_fma(-fn, 2.02226624871116645580e-21, r);
+    // (|fn| < 2^20 for every argument this is called with, see Acrobot; beyond int's range -- only the discarded first
+    // pass of a lane that step() sends through its rare branch, or a NaN state -- v_cvt_i32_f64 saturates / gives 0 and
+    // the results are NaN or unused either way.  n by adding 1.5 * 2^52 and reading the low mantissa bits needs no
+    // conversion at all, but measured 5 us slower per Acrobot rollout: hipcc's schedule again.)
     const int n = (int)fn;
     double s, c;
     sincos_small(r, s, c);
