@@ -544,11 +544,26 @@ template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
         if (!JOINT) {
             for (int k = threadIdx.x; k < BB16_WORDS; k += ROLLOUT_BLOCK) smem[k] = params[BB16_WORDS + k];
         }
-        for (int k = threadIdx.x; k < HL_WORDS; k += ROLLOUT_BLOCK) {     // k = (jo * 16 + r) * 64 + lane
+        // k = (jo * 16 + r) * 64 + lane; thread tid takes k = tid + 256 i, so jo = i / 4 is a compile-time constant of
+        // the unrolled loop: no branch inside it, every load of the table issued before the first is waited for.  (As a
+        // run-time loop with the DIFF test inside, hipcc made it 32 trips of load - wait - store: 8.5 us at the head
+        // of every launch, tools/rollout_timeline.py.)  Rows no forward pass reads are not copied.
+        static_assert(HL_WORDS % ROLLOUT_BLOCK == 0 && ROLLOUT_BLOCK == 256, "head-table fill: four trips per (j, op) row");
+        float hv[HL_WORDS / ROLLOUT_BLOCK];
+#pragma unroll
+        for (int i = 0; i < HL_WORDS / ROLLOUT_BLOCK; ++i) {
+            const int k = (int)threadIdx.x + i * ROLLOUT_BLOCK, j = i >> 3;
+            hv[i] = 0.0f;
+            if (j < NP || j == 3) {
+                hv[i] = heads[k];
+                if (DIFF && j == 0) hv[i] = heads[k + 2 * 16 * 64] - hv[i];   // row 0 <- row 1 - row 0
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HL_WORDS / ROLLOUT_BLOCK; ++i) {
+            const int k = (int)threadIdx.x + i * ROLLOUT_BLOCK, j = i >> 3;
             const int l = k & 63, r = (k >> 6) & 15, jo = k >> 10;
-            float v = heads[k];
-            if (DIFF && (jo >> 1) == 0) v = heads[k + 2 * 16 * 64] - v;   // row 0 <- row 1 - row 0
-            shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = v;
+            if (j < NP || j == 3) shl[((jo * 4 + (r >> 2)) * 64 + l) * 4 + (r & 3)] = hv[i];
         }
         __syncthreads();                           // the only barrier: waves are independent from here on
         V.p = smem;
@@ -573,9 +588,17 @@ template <class S, int OBS_, int A_, bool JOINT_, int ETILES_> struct NetF16 {
 // on the action (the pole angle's sin / cos, the products of the old state) up beside the network's MFMA chains
 // instead of starting it after the last head FMA.  A/B at C2, alternating fresh processes: 427.5 -> 417.2 us per
 // rollout (f16-split), 601.6 -> 599.6 us (bf16x3).  Same instructions per lane, bit-identical results.
+#ifdef PPO_ROLLOUT_TIMELINE                        // development (tools/rollout_timeline.py): where a launch's fixed part goes
+__device__ unsigned long long g_rollout_timeline[4096 * 8];
+#define TL_MARK(k) do { if ((threadIdx.x & 63) == 0) { const size_t w_ = ((size_t)blockIdx.x * ROLLOUT_BLOCK + threadIdx.x) >> 6; \
+    if (w_ < 4096) g_rollout_timeline[w_ * 8 + (k)] = wall_clock64(); } } while (0)
+#else
+#define TL_MARK(k) do { } while (0)
+#endif
 template <class Env, class Net, bool DRAWS, bool FULL = false>
 __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const float *__restrict__ params)
 {
+    TL_MARK(0);
     constexpr int OBS = Env::OBS, A = Net::A;
     constexpr bool JOINT = Net::JOINT;
     static_assert(OBS % 2 == 0 && A <= 3, "fragment layout assumes an even input width and <= 3 actions");
@@ -597,6 +620,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     __shared__ __attribute__((aligned(16))) float smem[Net::LDS_WORDS];
     Net net;
     net.load(params, smem, lane);
+    TL_MARK(1);
 
     EnvRegs e;
     load_env(e, a.env, nn);
@@ -616,6 +640,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
     // Everything loaded above has arrived before the loop starts, so that no vmcnt wait is needed
     // inside it: there it would also wait for the previous step's stores (vmcnt counts both).
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), other counters untouched
+    TL_MARK(2);
     int pend_t = -1;                               // row of this env's truncation still waiting for its bootstrap value
     // Second network pass over the terminal observations of the envs with a pending truncation.  always_inline: given
     // a third call site hipcc made it a real function, reached by s_swappc with the network's registers handed over
@@ -736,7 +761,9 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         }
     }
     for (int t = t0; t < a.T; ++t) step_body(std::false_type{}, t);
+    TL_MARK(3);
     if (__any(pend_t >= 0)) settle();
+    TL_MARK(4);
     if (live) {
         store_env(e, a.env, n);
         store_obs<Env>(a.obs_io, n, obs);
@@ -745,6 +772,7 @@ __global__ void __launch_bounds__(ROLLOUT_BLOCK) k_rollout(RolloutArgs a, const 
         const double w = wave_sum(live ? (double)rsum : 0.0);
         if (lane == 0) atomicAdd(a.reward_sum, w);
     }
+    TL_MARK(5);
 }
 
 template <class Env, class Net> void launch_net(const RolloutArgs &a, unsigned grid, hipStream_t s)
@@ -876,3 +904,10 @@ int ppo_rollout_fused_packed(int kind, double *state, int *elapsed, float *ep_re
 }
 
 }  // extern "C"
+
+#ifdef PPO_ROLLOUT_TIMELINE
+extern "C" int ppo_rollout_timeline_read(unsigned long long *dst, int words)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rollout_timeline), (size_t)words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
