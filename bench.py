@@ -456,11 +456,11 @@ def main():
             "hbm_write_gbs": ro_bytes / (ro_ms * 1e-3) / 1e9,
             # VALU issue: instructions per wave and step from the committed PMC summary (SQ_INSTS_VALU / waves / T,
             # CartPole joint, 64-env waves) against one wave64 instruction per SIMD every four cycles at 2.4 GHz
-            "valu_insts_per_wave_step": (1002 if (kind == "cartpole" and N > 32768) else None),
-            "valu_issue_frac": ((1002 * waves * T / (ro_ms * 1e-3)) / (1024 * 2.4e9 / 4)
+            "valu_insts_per_wave_step": (978 if (kind == "cartpole" and N > 32768) else None),
+            "valu_issue_frac": ((978 * waves * T / (ro_ms * 1e-3)) / (1024 * 2.4e9 / 4)
                                 if (kind == "cartpole" and N > 32768) else None),
             "note": "neither an HBM- nor an MFMA-bound kernel: by PMC (profiles/r03_rollout_pmc_f16_split.txt) "
-                    "the VALU is active 71 % of the wave cycles (1002 instructions per wave and step: tanh, operand "
+                    "the VALU is active 73 % of the wave cycles (978 instructions per wave and step: tanh, operand "
                     "splits, heads, f64 physics, Philox), the 60 f16 MFMAs per wave and step are busy 25 %; duration "
                     "from the dispatch's own start/stop timestamps (step_breakdown_us)"}
         if world == 1 and not args.no_cpu_baseline:
