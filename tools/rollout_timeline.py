@@ -1,7 +1,7 @@
 """Where the whole-rollout kernel's fixed per-launch time goes: per-wave wall-clock marks (100 MHz counter) at kernel
 entry, after the parameter load / LDS fill, before the loop, after the loop, after the last bootstrap pass, at the end.
 Needs a library built with -DPPO_ROLLOUT_TIMELINE (tools/build_variant.sh timeline -DPPO_ROLLOUT_TIMELINE).
-usage: rollout_timeline.py variants/libtimeline.so [kind]   (development aid)"""
+usage: rollout_timeline.py variants/libtimeline.so [kind] [joint]   (development aid; PPO_AMD_NET picks the network mode)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ppo_amd import _lib
@@ -11,10 +11,11 @@ import torch
 from ppo_amd import Agent, SyncVecEnv
 from ppo_amd.envs import DeviceEnv
 kind = sys.argv[2] if len(sys.argv) > 2 else "cartpole"
+joint = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 N, T = 65536, 128
 probe = DeviceEnv(kind)
 torch.manual_seed(0)
-agent = Agent(probe.observation_space, probe.action_space, 0, 1, "cuda")
+agent = Agent(probe.observation_space, probe.action_space, 0, joint, "cuda")
 ve = SyncVecEnv(lambda: DeviceEnv(kind), N, T, 0, 0.0, agent, seed=0)
 ve._device_episode_stats = lambda **kw: None
 for _ in range(60): ve.rollout()
