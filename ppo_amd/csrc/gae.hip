@@ -490,10 +490,18 @@ __device__ __forceinline__ void consume_word_block(const WordBlock<VEC> &b, cons
 
 // Column per lane, one flag word (16 rows) per block, STAGES blocks in flight: the form for narrow batches
 // (too few columns to give four waves per 64 columns something to overlap with) and the tuning baseline.
+#ifdef PPO_GAE_TIMELINE                            // development (tools/gae_timeline.py): the launch's ramp and drain per wave
+__device__ unsigned long long g_gae_timeline[8192 * 4];
+#define TLG_MARK(k) do { if ((threadIdx.x & 63) == 0) { const size_t w_ = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; \
+    if (w_ < 8192) g_gae_timeline[w_ * 4 + (k)] = wall_clock64(); } } while (0)
+#else
+#define TLG_MARK(k) do { } while (0)
+#endif
 template <int VEC, int STAGES, bool FULL>
 __global__ void __launch_bounds__(256) k_gae_words(GaeArgs a)
 {
     static_assert(STAGES == 2 || STAGES == 3, "");
+    TLG_MARK(0);
     const size_t col = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (col >= (size_t)a.N) return;
     float nv[VEC], na[VEC];
@@ -509,10 +517,18 @@ __global__ void __launch_bounds__(256) k_gae_words(GaeArgs a)
         if (STAGES == 3 && q >= 2) load_word_block<VEC, true>(f2, a, col, q - 2);
         if (q >= 1) load_ev_word<VEC>(e1, f1, a, col, q - 1);
         consume_word_block<VEC, FULL>(f0, e0, a, col, q, nv, na);
+#ifdef PPO_GAE_TIMELINE
+        if (q == (a.T + FLAG_ROWS - 1) / FLAG_ROWS - 1) TLG_MARK(1);
+#endif
         f0 = f1; e0 = e1;
         if (STAGES == 3) f1 = f2;
         else if (q >= 2) load_word_block<VEC, true>(f1, a, col, q - 2);
     }
+    TLG_MARK(2);
+#ifdef PPO_GAE_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // every store of the wave has landed
+    TLG_MARK(3);
+#endif
 }
 
 // Buffer addressing for the time-split kernel: one resource descriptor per array (4 SGPRs), the row's byte offset in
@@ -1066,3 +1082,10 @@ int ppo_gae_ragged(const float *rewards, const float *values, const float *end_v
 }
 
 }  // extern "C"
+
+#ifdef PPO_GAE_TIMELINE
+extern "C" int ppo_gae_timeline_read(unsigned long long *dst, int words)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gae_timeline), (size_t)words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
