@@ -38,8 +38,10 @@ extern "C" {
 /* 2: the sampling stream of ppo_categorical_sample / ppo_rollout_fused draws one Philox block per FOUR policy
  *    steps (counter = step / 4, word = step % 4; version 1 drew one block per step), so a run resumed across the
  *    two versions samples different actions; PPO_NET_BF16X3 added; private hooks changed.
- * 3: ppo_episode_stats_incremental_ints, ppo_episode_stats_ints_hist_offset added; nothing else changed. */
-#define PPO_AMD_ABI_VERSION 3
+ * 3: ppo_episode_stats_incremental_ints, ppo_episode_stats_ints_hist_offset added; nothing else changed.
+ * 4: the direct histogram behind ppo_episode_stats_ints_hist_offset is kept as PPO_STATS_INTS_REPLICAS partial
+ *    histograms (their u32 sum is the window's); nothing else changed. */
+#define PPO_AMD_ABI_VERSION 4
 
 #define PPO_ENV_CARTPOLE 0 /* CartPole-v1: obs_dim 4, actions {0,1}   */
 #define PPO_ENV_ACROBOT 1  /* Acrobot-v1:  obs_dim 6, actions {0,1,2} */
@@ -428,10 +430,12 @@ int ppo_episode_stats_incremental(const float *ret_ring, const int *len_ring, co
  * whenever the rings were rewritten by anything else), but the two forms keep different histograms in it: a state
  * block belongs to ONE of the two entry points -- zero-fill it when switching.
  * Data-parallel ranks add up the direct histograms (one all-reduce) and read the job's order statistics off the sum:
- * at byte offset ppo_episode_stats_ints_hist_offset() of the state, u32 [PPO_STATS_INTS_RET_BINS +
- * PPO_STATS_INTS_LEN_BINS]: word PPO_STATS_INTS_RET_ZERO + r counts the window's returns equal to r, word
- * PPO_STATS_INTS_RET_BINS + l its lengths equal to l.
+ * at byte offset ppo_episode_stats_ints_hist_offset() of the state, u32 [PPO_STATS_INTS_REPLICAS][PPO_STATS_INTS_RET_BINS +
+ * PPO_STATS_INTS_LEN_BINS] -- partial histograms, kept apart so that the workgroups' updates do not queue on the same
+ * words; their sum modulo 2^32 (a partial count may have wrapped below zero) is the window's histogram: word
+ * PPO_STATS_INTS_RET_ZERO + r counts the returns equal to r, word PPO_STATS_INTS_RET_BINS + l the lengths equal to l.
  */
+#define PPO_STATS_INTS_REPLICAS 8
 #define PPO_STATS_INTS_RET_ZERO 512
 #define PPO_STATS_INTS_RET_BINS 1280
 #define PPO_STATS_INTS_LEN_BINS 768

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PPO_AMD_LIB") or os.path.join(_HERE, "libppo_amd.so")   # (PPO_AMD_LIB: A/B of two builds, development)
 
-ABI_VERSION = 3   # include/ppo_amd.h: PPO_AMD_ABI_VERSION
+ABI_VERSION = 4   # include/ppo_amd.h: PPO_AMD_ABI_VERSION
 
 _vp, _i, _l, _d, _u64, _sz = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_uint64, C.c_size_t
 

@@ -755,6 +755,12 @@ constexpr int INTS_R0 = PPO_STATS_INTS_RET_ZERO;           // bin of return 0
 constexpr int INTS_RBINS = PPO_STATS_INTS_RET_BINS;        // 1280 = 64 lanes x 20 (1025 used)
 constexpr int INTS_LBINS = PPO_STATS_INTS_LEN_BINS;        // 768 = 64 lanes x 12 (513 used)
 constexpr int INTS_WORDS = INTS_RBINS + INTS_LBINS;
+// The persistent histogram is kept as INTS_REPL partial histograms whose u32 sum (mod 2^32: a partial count may have
+// wrapped below zero) is the window's: a workgroup flushes into copy blockIdx % INTS_REPL.  With ONE copy the flush
+// was 5.0 us of the launch's 16 -- 256 workgroups' atomics queueing on the same ~100 hot bins (returns and lengths of
+// 8..60 for a fresh policy), tools/stats_timeline.py -- with eight it is 1.2 us; the last workgroup reads eight copies
+// instead of one in the same round trip.
+constexpr int INTS_REPL = PPO_STATS_INTS_REPLICAS;
 static_assert(INTS_RBINS % 256 == 0 && INTS_LBINS % 256 == 0 && INTS_R0 * 2 + 1 <= INTS_RBINS, "bin layout");
 
 struct IntsState {                // head of the state block (the first SEL_STATE_BYTES bytes), zero-filled by the caller
@@ -776,6 +782,12 @@ __device__ __forceinline__ void ints_apply(uint32_t *h, uint32_t sign, float r, 
     }
 }
 
+#ifdef PPO_STATS_TIMELINE                          // development (tools/stats_timeline.py): the launch's phases per workgroup
+__device__ unsigned long long g_stats_timeline[256 * 8];
+#define TLS_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_stats_timeline[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TLS_MARK(k) do { } while (0)
+#endif
 __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr_ints(const float *__restrict__ ret_ring, const int *__restrict__ len_ring,
                                                                 const int *__restrict__ ring_cnt, int ring, int N,
                                                                 IntsState *st, uint32_t *hist, IncrBufs ib, double *stats5)
@@ -788,6 +800,7 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr_ints(const float *__
     __shared__ int s_c0[INCR_ENVS], s_c1[INCR_ENVS];
     __shared__ uint32_t s_wsum[INCR_ENVS / 64];
     uint2 *__restrict__ shadow = ib.shadow;
+    TLS_MARK(0);
     for (int k = threadIdx.x; k < INTS_WORDS; k += SEL_HBLOCK) h[k] = 0u;
 
     // the slots written since the last call, exactly as in k_sel_incr
@@ -824,6 +837,7 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr_ints(const float *__
             if (threadIdx.x == INCR_ENVS - 1) s_first[INCR_ENVS] = before + incl;
         }
         __syncthreads();
+        TLS_MARK(1);
         const uint32_t items = s_first[INCR_ENVS];
         for (uint32_t it0 = threadIdx.x; it0 < items; it0 += 2 * SEL_HBLOCK) {
             size_t at[2];
@@ -862,28 +876,44 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr_ints(const float *__
             }
         }
     }
+    TLS_MARK(2);
     bad = (int)wave_sum((double)bad);
     if ((threadIdx.x & 63) == 0 && bad != 0)
         __hip_atomic_fetch_add(&st->bad, (long long)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    uint32_t *mine = hist + (blockIdx.x % INTS_REPL) * INTS_WORDS;
     for (int k = threadIdx.x; k < INTS_WORDS; k += SEL_HBLOCK) {
         const uint32_t v = h[k];
-        if (v) atomicAdd(&hist[k], v);
+        if (v) atomicAdd(&mine[k], v);
     }
     // last workgroup to flush makes the statistics (see k_sel for why atomics + vmcnt(0) and no fence)
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
     __syncthreads();
+    TLS_MARK(3);
     if (threadIdx.x == 0)
         s_is_last = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
+    TLS_MARK(4);
     if (!s_is_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    SelFetch<INTS_WORDS> f;
-    f.fetch(hist);
+    SelFetch<INTS_WORDS> f;                                  // the sum of the copies, every load in flight at once
+    {
+        SelFetch<INTS_WORDS> part[INTS_REPL];
+#pragma unroll
+        for (int c = 0; c < INTS_REPL; ++c) part[c].fetch(hist + c * INTS_WORDS);
+#pragma unroll
+        for (int i = 0; i < SelFetch<INTS_WORDS>::PER; ++i) {
+            uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+            for (int c = 0; c < INTS_REPL; ++c) { lo += (uint32_t)part[c].v[i]; hi += (uint32_t)(part[c].v[i] >> 32); }
+            f.v[i] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        }
+    }
     const long long bad_now = threadIdx.x == 0 ? __hip_atomic_load(&st->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     __syncthreads();                                         // every thread is done with the deltas
     f.template store<false>(h);
     __syncthreads();
+    TLS_MARK(5);
     const int t = wv;                                        // waves 0..8: one target each
     if (t < SEL_SWAVES) {
         unsigned long long n = 0, rank = 0;
@@ -915,6 +945,7 @@ __global__ void __launch_bounds__(SEL_HBLOCK, 1) k_sel_incr_ints(const float *__
     stats5[2] = lerp_pair(v[2], v[3], n, 0.50);
     stats5[3] = lerp_pair(v[4], v[5], n, 0.95);
     stats5[4] = lerp_pair(v[7], v[8], n, 0.50);
+    TLS_MARK(6);
 }
 
 }  // namespace
@@ -1012,7 +1043,7 @@ int ppo_episode_stats_incremental_ints(const float *ret_ring, const int *len_rin
     PPO_REQUIRE(N >= 0 && ring > 0 && (unsigned long long)N * (unsigned long long)ring < 0xFFFFFFFFull);
     PPO_REQUIRE(stats5 && ppo_aligned(stats5, 8));
     PPO_REQUIRE(state && state_bytes >= incr_state_bytes(N, ring) && ppo_aligned(state, 16));
-    static_assert(SEL_STATE_BYTES + INTS_WORDS * sizeof(uint32_t) <= INCR_HEAD_BYTES, "direct histogram fits the state head");
+    static_assert(SEL_STATE_BYTES + INTS_REPL * INTS_WORDS * sizeof(uint32_t) <= INCR_HEAD_BYTES, "direct histograms fit the state head");
     if (N == 0) return 0;
     PPO_REQUIRE(ret_ring && len_ring && ring_cnt);
     char *base = static_cast<char *>(state);
@@ -1030,3 +1061,10 @@ int ppo_episode_stats_incremental_ints(const float *ret_ring, const int *len_rin
 }
 
 }  // extern "C"
+
+#ifdef PPO_STATS_TIMELINE
+extern "C" int ppo_stats_timeline_read(unsigned long long *dst, int words)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stats_timeline), (size_t)words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -569,8 +569,10 @@ class SyncVecEnv:
         RB, R0 = _lib_const("PPO_STATS_INTS_RET_BINS"), _lib_const("PPO_STATS_INTS_RET_ZERO")
         LB = _lib_const("PPO_STATS_INTS_LEN_BINS")
         off = lib.ppo_episode_stats_ints_hist_offset()
-        h = self._stats_state[off:off + (RB + LB) * 4].view(torch.int32).clone()
-        h = ppo_dist.sum_tensor(h, "ep_hist_ints").cpu().numpy().view(np.uint32).astype(np.int64)
+        reps = _lib_const("PPO_STATS_INTS_REPLICAS")       # partial histograms; their sum mod 2^32 is this rank's window
+        parts = self._stats_state[off:off + reps * (RB + LB) * 4].view(torch.int32).view(reps, RB + LB)
+        h = parts.to(torch.int64).sum(0) & 0xFFFFFFFF      # this rank's counts (int64: the job's sum cannot wrap)
+        h = ppo_dist.sum_tensor(h, "ep_hist_ints").cpu().numpy()
         n = int(h[:RB].sum())
         if n == 0:                                         # no episode has finished anywhere yet
             return job_reward
@@ -709,7 +711,7 @@ class SyncVecEnv:
 
 
 _LIB_CONSTS = {"PPO_STATS_INTS_RET_ZERO": 512, "PPO_STATS_INTS_RET_BINS": 1280, "PPO_STATS_INTS_LEN_BINS": 768,
-               "PPO_STATS_INTS_LEN_MAX": 512}      # include/ppo_amd.h (tests/test_abi.py checks them against the header)
+               "PPO_STATS_INTS_LEN_MAX": 512, "PPO_STATS_INTS_REPLICAS": 8}      # include/ppo_amd.h (tests/test_abi.py checks them against the header)
 
 
 def _lib_const(name: str) -> int:

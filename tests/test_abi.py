@@ -45,7 +45,7 @@ def test_every_exported_symbol_is_declared_or_listed_private():
 
 def test_abi_version_and_obs_dim():
     lib = _lib.load()
-    assert lib.ppo_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.ppo_abi_version() == _lib.ABI_VERSION == 4
     assert lib.ppo_env_obs_dim(0) == 4 and lib.ppo_env_obs_dim(1) == 6 and lib.ppo_env_obs_dim(7) == -1
 
 
